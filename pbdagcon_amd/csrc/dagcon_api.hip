@@ -1,0 +1,667 @@
+// dagcon_api.hip -- host side of the C ABI (include/dagcon.h).
+//
+// Owns the HIP stream, the HBM arenas and the launch sequence of the hot path
+//   a1 k_count, k_normalize | a2 k_carve, k_init_nodes, k_emit, k_lists |
+//   b  k_merge              | c  k_bestpath
+// There is no CPU fallback anywhere in this file: without a HIP device
+// dagcon_create fails with DAGCON_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/dagcon.h"
+#include "dagcon_dev.h"
+#include "k_build.hip.h"
+#include "k_merge.hip.h"
+#include "k_bestpath.hip.h"
+
+namespace {
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+struct Ctx {
+    dagcon_opts opts;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    std::string err;
+    bool uploaded = false, ran = false, fetched = false;
+
+    // host copy of the filtered batch
+    uint32_t T = 0, A = 0;
+    uint32_t max_k = 0, max_tlen = 0;
+    uint64_t sum_len = 0, sum_bb = 0, mat_cells = 0, blob_bytes = 0;
+    bool have_bb = false;
+    std::vector<uint32_t> h_tlen, h_aln_len, h_aln_start, h_aln_tgt;
+    std::vector<uint64_t> h_aln_begin, h_aln_off, h_mat_base, h_bbv_base, h_bb_off;
+    std::vector<uint8_t> h_tactive;
+
+    // device buffers
+    DevBuf d_q, d_t, d_aln_off, d_aln_len, d_aln_start, d_aln_tgt, d_tlen, d_aln_begin, d_tactive,
+        d_bb, d_bb_off, d_mat_base, d_bbv_base;
+    DevBuf d_nmis, d_norm_off, d_n_lo, d_n_hi, d_n_start, d_n_ins, d_n_del, d_ins_base, d_norm;
+    DevBuf d_node_base, d_n_nodes, d_pool_base, d_pool_size, d_pool_top;
+    DevBuf d_matA, d_matD, d_cov, d_bvote;
+    DevBuf d_hot, d_lists, d_weight, d_bbpos, d_pending, d_best, d_queue, d_score, d_cns_tmp;
+    DevBuf d_pool, d_stk;
+    DevBuf d_cns, d_cns_off, d_cns_len, d_seg_first, d_n_seg, d_seg_r0, d_seg_r1, d_st;
+
+    uint64_t norm_cap = 0, node_cap = 0, pool_cap = 0, cns_cap = 0, seg_cap = 0;
+    uint32_t stk_words = 16384, growth_pct = 100;
+
+    DgStatus h_st;
+    dagcon_timings tm;
+
+    // results (host)
+    std::vector<uint64_t> r_seg_begin, r_seq_off, r_cns_off, r_seg_first;
+    std::vector<int32_t> r_range0, r_range1, r_tmp0, r_tmp1;
+    std::vector<uint32_t> r_seq_len, r_cns_len, r_n_seg;
+    std::vector<char> r_blob;
+
+    // debug dump storage
+    std::vector<uint8_t> g_base, g_deleted;
+    std::vector<int32_t> g_weight, g_cov, g_out_dst, g_out_cnt, g_in_src;
+    std::vector<uint32_t> g_out_begin, g_in_begin;
+};
+
+int fail(Ctx *c, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf;
+    return code;
+}
+
+#define HIPCHK(c, call)                                                                    \
+    do {                                                                                   \
+        hipError_t _e = (call);                                                            \
+        if (_e != hipSuccess)                                                              \
+            return fail((c), DAGCON_ERR_HIP, "%s failed: %s (%s:%d)", #call,               \
+                        hipGetErrorString(_e), __FILE__, __LINE__);                        \
+    } while (0)
+
+int ensure(Ctx *c, DevBuf &b, size_t bytes) {
+    if (bytes == 0) bytes = 16;
+    if (b.cap >= bytes) return DAGCON_OK;
+    if (b.p) { (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
+    size_t want = bytes + bytes / 16 + 256;
+    hipError_t e = hipMalloc(&b.p, want);
+    if (e != hipSuccess) {
+        b.p = nullptr;
+        return fail(c, DAGCON_ERR_WORKSPACE, "hipMalloc(%zu bytes) failed: %s", want, hipGetErrorString(e));
+    }
+    b.cap = want;
+    return DAGCON_OK;
+}
+
+#define ENSURE(c, buf, bytes)                                \
+    do {                                                     \
+        int _r = ensure((c), (buf), (size_t)(bytes));        \
+        if (_r != DAGCON_OK) return _r;                      \
+    } while (0)
+
+template <typename T>
+int upload_vec(Ctx *c, DevBuf &b, const std::vector<T> &v) {
+    ENSURE(c, b, v.size() * sizeof(T));
+    if (!v.empty()) HIPCHK(c, hipMemcpyAsync(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, c->stream));
+    return DAGCON_OK;
+}
+
+void free_buf(DevBuf &b) {
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr; b.cap = 0;
+}
+
+int ensure_arenas(Ctx *c) {
+    ENSURE(c, c->d_norm, c->norm_cap * sizeof(uint16_t));
+    ENSURE(c, c->d_hot, c->node_cap * sizeof(DgHot));
+    ENSURE(c, c->d_lists, c->node_cap * sizeof(DgLists));
+    ENSURE(c, c->d_weight, c->node_cap * 4);
+    ENSURE(c, c->d_bbpos, c->node_cap * 4);
+    ENSURE(c, c->d_pending, c->node_cap * 4);
+    ENSURE(c, c->d_best, c->node_cap * 4);
+    ENSURE(c, c->d_queue, c->node_cap * 4);
+    ENSURE(c, c->d_score, c->node_cap * 4);
+    ENSURE(c, c->d_cns_tmp, c->node_cap);
+    ENSURE(c, c->d_pool, c->pool_cap * 4);
+    ENSURE(c, c->d_stk, (uint64_t)c->T * c->stk_words * 4);
+    ENSURE(c, c->d_cns, c->cns_cap);
+    ENSURE(c, c->d_seg_r0, c->seg_cap * 4);
+    ENSURE(c, c->d_seg_r1, c->seg_cap * 4);
+    return DAGCON_OK;
+}
+
+void fill_params(Ctx *c, DgParams &p) {
+    memset(&p, 0, sizeof p);
+    p.q = (const uint8_t *)c->d_q.p; p.t = (const uint8_t *)c->d_t.p;
+    p.aln_off = (const uint64_t *)c->d_aln_off.p;
+    p.aln_len = (const uint32_t *)c->d_aln_len.p;
+    p.aln_start = (const uint32_t *)c->d_aln_start.p;
+    p.aln_tgt = (const uint32_t *)c->d_aln_tgt.p;
+    p.tlen = (const uint32_t *)c->d_tlen.p;
+    p.aln_begin = (const uint64_t *)c->d_aln_begin.p;
+    p.tactive = (const uint8_t *)c->d_tactive.p;
+    p.bb = c->have_bb ? (const uint8_t *)c->d_bb.p : nullptr;
+    p.bb_off = (const uint64_t *)c->d_bb_off.p;
+    p.mat_base = (const uint64_t *)c->d_mat_base.p;
+    p.bbv_base = (const uint64_t *)c->d_bbv_base.p;
+    p.T = c->T; p.A = c->A;
+    p.trim = c->opts.trim; p.min_len = c->opts.min_len;
+    p.min_weight = c->opts.min_weight < 0 ? (int32_t)c->opts.min_cov : c->opts.min_weight;
+    p.flags = c->opts.flags;
+    p.max_k = c->max_k; p.max_tlen = c->max_tlen;
+    p.nmis = (uint32_t *)c->d_nmis.p; p.norm_off = (uint64_t *)c->d_norm_off.p;
+    p.n_lo = (uint32_t *)c->d_n_lo.p; p.n_hi = (uint32_t *)c->d_n_hi.p;
+    p.n_start = (uint32_t *)c->d_n_start.p; p.n_ins = (uint32_t *)c->d_n_ins.p;
+    p.n_del = (uint32_t *)c->d_n_del.p; p.ins_base = (uint32_t *)c->d_ins_base.p;
+    p.norm = (uint16_t *)c->d_norm.p; p.norm_cap = c->norm_cap;
+    p.node_base = (uint64_t *)c->d_node_base.p; p.n_nodes = (uint32_t *)c->d_n_nodes.p;
+    p.pool_base = (uint64_t *)c->d_pool_base.p; p.pool_size = (uint32_t *)c->d_pool_size.p;
+    p.pool_top = (uint32_t *)c->d_pool_top.p;
+    p.matA = (uint32_t *)c->d_matA.p; p.matD = (uint32_t *)c->d_matD.p;
+    p.cov = (int32_t *)c->d_cov.p; p.bvote = (uint32_t *)c->d_bvote.p;
+    p.hot = (DgHot *)c->d_hot.p; p.lists = (DgLists *)c->d_lists.p;
+    p.weight = (int32_t *)c->d_weight.p; p.bbpos = (int32_t *)c->d_bbpos.p;
+    p.pending = (int32_t *)c->d_pending.p; p.best = (int32_t *)c->d_best.p;
+    p.queue = (int32_t *)c->d_queue.p; p.score = (float *)c->d_score.p;
+    p.cns_tmp = (uint8_t *)c->d_cns_tmp.p; p.node_cap = c->node_cap;
+    p.pool = (uint32_t *)c->d_pool.p; p.pool_cap = c->pool_cap;
+    p.stk = (int32_t *)c->d_stk.p; p.stk_words = c->stk_words; p.growth_pct = c->growth_pct;
+    p.cns = (uint8_t *)c->d_cns.p; p.cns_cap = c->cns_cap;
+    p.cns_off = (uint64_t *)c->d_cns_off.p; p.cns_len = (uint32_t *)c->d_cns_len.p;
+    p.seg_first = (uint64_t *)c->d_seg_first.p; p.n_seg = (uint32_t *)c->d_n_seg.p;
+    p.seg_r0 = (int32_t *)c->d_seg_r0.p; p.seg_r1 = (int32_t *)c->d_seg_r1.p;
+    p.seg_cap = c->seg_cap;
+    p.st = (DgStatus *)c->d_st.p;
+}
+
+int launch_all(Ctx *c) {
+    int r = ensure_arenas(c);
+    if (r != DAGCON_OK) return r;
+    DgParams p;
+    fill_params(c, p);
+    hipStream_t s = c->stream;
+    HIPCHK(c, hipMemsetAsync(c->d_st.p, 0, sizeof(DgStatus), s));
+    HIPCHK(c, hipMemsetAsync(c->d_cns_len.p, 0, (size_t)c->T * 4, s));
+    HIPCHK(c, hipMemsetAsync(c->d_n_seg.p, 0, (size_t)c->T * 4, s));
+    HIPCHK(c, hipEventRecord(c->ev[0], s));
+    if (c->A > 0) {
+        hipLaunchKernelGGL(k_count, dim3(c->A), dim3(256), 0, s, p);
+        hipLaunchKernelGGL(k_normalize, dim3((c->A + 63) / 64), dim3(64), 0, s, p);
+    }
+    HIPCHK(c, hipEventRecord(c->ev[1], s));
+    if (c->mat_cells) {
+        HIPCHK(c, hipMemsetAsync(c->d_matA.p, 0, c->mat_cells * 4, s));
+        HIPCHK(c, hipMemsetAsync(c->d_matD.p, 0, c->mat_cells * 4, s));
+    }
+    hipLaunchKernelGGL(k_carve, dim3(1), dim3(1024), 0, s, p);
+    if (c->T > 0) {
+        hipLaunchKernelGGL(k_init_nodes, dim3(c->T, (c->max_tlen + 2 + 255) / 256), dim3(256), 0, s, p);
+        if (c->A > 0) hipLaunchKernelGGL(k_emit, dim3((c->A + 63) / 64), dim3(64), 0, s, p);
+        const size_t lds = (size_t)4 * 2 * (c->max_k + 2) * sizeof(int32_t);
+        if (lds > 65536)
+            HIPCHK(c, hipFuncSetAttribute((const void *)k_lists, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_lists, dim3(c->T, (c->max_tlen + 2 + 3) / 4), dim3(256), lds, s, p);
+    }
+    HIPCHK(c, hipEventRecord(c->ev[2], s));
+    if (c->T > 0 && !(c->opts.flags & DAGCON_FLAG_STOP_AFTER_BUILD))
+        hipLaunchKernelGGL(k_merge, dim3(c->T), dim3(64), 0, s, p);
+    HIPCHK(c, hipEventRecord(c->ev[3], s));
+    if (c->T > 0 && !(c->opts.flags & (DAGCON_FLAG_STOP_AFTER_BUILD | DAGCON_FLAG_STOP_AFTER_MERGE)))
+        hipLaunchKernelGGL(k_bestpath, dim3(c->T), dim3(64), 0, s, p);
+    HIPCHK(c, hipEventRecord(c->ev[4], s));
+    HIPCHK(c, hipGetLastError());
+    return DAGCON_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dagcon_abi_version(void) { return DAGCON_ABI_VERSION; }
+
+void dagcon_default_opts(dagcon_opts *o) {
+    if (!o) return;
+    memset(o, 0, sizeof *o);
+    o->min_cov = 6; o->min_len = 500; o->trim = 50; o->min_weight = -1; o->device = 0; o->flags = 0;
+}
+
+const char *dagcon_last_error(const dagcon_ctx *ctx) {
+    return ctx ? reinterpret_cast<const Ctx *>(ctx)->err.c_str() : "null context";
+}
+
+int dagcon_create(const dagcon_opts *opts, dagcon_ctx **out) {
+    if (!opts || !out) return DAGCON_ERR_INVALID_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return DAGCON_ERR_NO_DEVICE;
+    if (opts->device < 0 || opts->device >= ndev) return DAGCON_ERR_NO_DEVICE;
+    Ctx *c = new Ctx();
+    c->opts = *opts;
+    c->device = opts->device;
+    memset(&c->tm, 0, sizeof c->tm);
+    memset(&c->h_st, 0, sizeof c->h_st);
+    if (hipSetDevice(c->device) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess) {
+        delete c;
+        return DAGCON_ERR_NO_DEVICE;
+    }
+    for (auto &e : c->ev)
+        if (hipEventCreate(&e) != hipSuccess) { delete c; return DAGCON_ERR_HIP; }
+    if (ensure(c, c->d_st, sizeof(DgStatus)) != DAGCON_OK) { delete c; return DAGCON_ERR_WORKSPACE; }
+    *out = reinterpret_cast<dagcon_ctx *>(c);
+    return DAGCON_OK;
+}
+
+void dagcon_destroy(dagcon_ctx *ctx) {
+    if (!ctx) return;
+    Ctx *c = reinterpret_cast<Ctx *>(ctx);
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    DevBuf *all[] = {&c->d_q, &c->d_t, &c->d_aln_off, &c->d_aln_len, &c->d_aln_start, &c->d_aln_tgt,
+                     &c->d_tlen, &c->d_aln_begin, &c->d_tactive, &c->d_bb, &c->d_bb_off, &c->d_mat_base,
+                     &c->d_bbv_base, &c->d_nmis, &c->d_norm_off, &c->d_n_lo, &c->d_n_hi, &c->d_n_start,
+                     &c->d_n_ins, &c->d_n_del, &c->d_ins_base, &c->d_norm, &c->d_node_base, &c->d_n_nodes,
+                     &c->d_pool_base, &c->d_pool_size, &c->d_pool_top, &c->d_matA, &c->d_matD, &c->d_cov,
+                     &c->d_bvote, &c->d_hot, &c->d_lists, &c->d_weight, &c->d_bbpos, &c->d_pending,
+                     &c->d_best, &c->d_queue, &c->d_score, &c->d_cns_tmp, &c->d_pool, &c->d_stk, &c->d_cns,
+                     &c->d_cns_off, &c->d_cns_len, &c->d_seg_first, &c->d_n_seg, &c->d_seg_r0, &c->d_seg_r1,
+                     &c->d_st};
+    for (DevBuf *b : all) free_buf(*b);
+    for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int dagcon_upload(dagcon_ctx *ctx, const dagcon_batch *b) {
+    if (!ctx || !b) return DAGCON_ERR_INVALID_ARG;
+    Ctx *c = reinterpret_cast<Ctx *>(ctx);
+    c->uploaded = c->ran = c->fetched = false;
+    const uint32_t T = b->n_targets;
+    if (T && (!b->tlen || !b->aln_begin)) return fail(c, DAGCON_ERR_INVALID_ARG, "tlen/aln_begin is NULL");
+    const uint64_t A_all = T ? b->aln_begin[T] : 0;
+    if (A_all && (!b->aln_start || !b->aln_off || !b->aln_len || !b->qstr || !b->tstr))
+        return fail(c, DAGCON_ERR_INVALID_ARG, "alignment arrays are NULL");
+    if (b->backbone && !b->backbone_off) return fail(c, DAGCON_ERR_INVALID_ARG, "backbone_off is NULL");
+    HIPCHK(c, hipSetDevice(c->device));
+
+    c->T = T;
+    c->h_tlen.assign(b->tlen, b->tlen + T);
+    c->h_aln_begin.assign(T + 1, 0);
+    c->h_tactive.assign(T, 0);
+    c->h_mat_base.assign(T, 0);
+    c->h_bbv_base.assign(T, 0);
+    c->h_bb_off.assign(T, 0);
+    c->h_aln_len.clear(); c->h_aln_start.clear(); c->h_aln_tgt.clear(); c->h_aln_off.clear();
+    c->max_k = 0; c->max_tlen = 0; c->sum_len = 0; c->sum_bb = 0; c->mat_cells = 0;
+    c->have_bb = b->backbone != nullptr;
+    uint64_t bb_bytes = 0;
+    const uint64_t min_cov = c->opts.min_cov;
+    for (uint32_t t = 0; t < T; t++) {
+        const uint64_t ab = b->aln_begin[t], ae = b->aln_begin[t + 1];
+        if (ae < ab) return fail(c, DAGCON_ERR_INVALID_ARG, "aln_begin not monotone at target %u", t);
+        const uint64_t k_all = ae - ab;
+        // main.cpp:66-72 (Reader) and :118 (Consensus): groups below min_cov are dropped
+        const bool active = k_all > 0 && k_all >= min_cov;
+        c->h_aln_begin[t] = c->h_aln_len.size();
+        if (!active) continue;
+        if (b->tlen[t] > 0x3FFFFFFFu) return fail(c, DAGCON_ERR_UNSUPPORTED, "tlen of target %u too large", t);
+        c->h_tactive[t] = 1;
+        for (uint64_t a = ab; a < ae; a++) {
+            const uint32_t len = b->aln_len[a];
+            if (b->aln_off[a] + len > b->blob_bytes)
+                return fail(c, DAGCON_ERR_INVALID_ARG, "alignment %llu runs past the blob", (unsigned long long)a);
+            if (len < c->opts.min_len) continue;       // main.cpp:132
+            c->h_aln_len.push_back(len);
+            c->h_aln_start.push_back(b->aln_start[a]);
+            c->h_aln_off.push_back(b->aln_off[a]);
+            c->h_aln_tgt.push_back(t);
+            c->sum_len += len;
+        }
+        const uint64_t k = c->h_aln_len.size() - c->h_aln_begin[t];
+        if (k > DAGCON_MAX_COVERAGE)
+            return fail(c, DAGCON_ERR_UNSUPPORTED, "target %u has %llu alignments (max %u)", t,
+                        (unsigned long long)k, DAGCON_MAX_COVERAGE);
+        c->max_k = std::max<uint32_t>(c->max_k, (uint32_t)k);
+        c->max_tlen = std::max(c->max_tlen, b->tlen[t]);
+        if ((uint64_t)b->tlen[t] + 2 > 4ull * 65535ull)
+            return fail(c, DAGCON_ERR_UNSUPPORTED, "tlen of target %u exceeds %u", t, 4u * 65535u - 2u);
+        c->h_mat_base[t] = c->mat_cells;
+        c->mat_cells += ((uint64_t)b->tlen[t] + 2) * k;
+        c->h_bbv_base[t] = c->sum_bb;
+        c->sum_bb += (uint64_t)b->tlen[t] + 2;
+        if (c->have_bb) {
+            c->h_bb_off[t] = b->backbone_off[t];
+            bb_bytes = std::max<uint64_t>(bb_bytes, b->backbone_off[t] + b->tlen[t]);
+        }
+    }
+    c->h_aln_begin[T] = c->h_aln_len.size();
+    if (c->h_aln_len.size() > 0xFFFFFFF0ull) return fail(c, DAGCON_ERR_UNSUPPORTED, "too many alignments");
+    c->A = (uint32_t)c->h_aln_len.size();
+    c->blob_bytes = b->blob_bytes;
+
+    // inputs -> HBM
+    ENSURE(c, c->d_q, b->blob_bytes);
+    ENSURE(c, c->d_t, b->blob_bytes);
+    if (b->blob_bytes) {
+        HIPCHK(c, hipMemcpyAsync(c->d_q.p, b->qstr, b->blob_bytes, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->d_t.p, b->tstr, b->blob_bytes, hipMemcpyHostToDevice, c->stream));
+    }
+    if (c->have_bb) {
+        ENSURE(c, c->d_bb, bb_bytes);
+        if (bb_bytes) HIPCHK(c, hipMemcpyAsync(c->d_bb.p, b->backbone, bb_bytes, hipMemcpyHostToDevice, c->stream));
+    }
+    int r;
+    if ((r = upload_vec(c, c->d_aln_off, c->h_aln_off))) return r;
+    if ((r = upload_vec(c, c->d_aln_len, c->h_aln_len))) return r;
+    if ((r = upload_vec(c, c->d_aln_start, c->h_aln_start))) return r;
+    if ((r = upload_vec(c, c->d_aln_tgt, c->h_aln_tgt))) return r;
+    if ((r = upload_vec(c, c->d_tlen, c->h_tlen))) return r;
+    if ((r = upload_vec(c, c->d_aln_begin, c->h_aln_begin))) return r;
+    if ((r = upload_vec(c, c->d_tactive, c->h_tactive))) return r;
+    if ((r = upload_vec(c, c->d_bb_off, c->h_bb_off))) return r;
+    if ((r = upload_vec(c, c->d_mat_base, c->h_mat_base))) return r;
+    if ((r = upload_vec(c, c->d_bbv_base, c->h_bbv_base))) return r;
+
+    // work arrays whose size the host knows
+    const size_t A4 = (size_t)c->A * 4, T4 = (size_t)T * 4;
+    ENSURE(c, c->d_nmis, A4); ENSURE(c, c->d_norm_off, (size_t)c->A * 8);
+    ENSURE(c, c->d_n_lo, A4); ENSURE(c, c->d_n_hi, A4); ENSURE(c, c->d_n_start, A4);
+    ENSURE(c, c->d_n_ins, A4); ENSURE(c, c->d_n_del, A4); ENSURE(c, c->d_ins_base, A4);
+    ENSURE(c, c->d_node_base, (size_t)T * 8); ENSURE(c, c->d_n_nodes, T4);
+    ENSURE(c, c->d_pool_base, (size_t)T * 8); ENSURE(c, c->d_pool_size, T4); ENSURE(c, c->d_pool_top, T4);
+    ENSURE(c, c->d_matA, c->mat_cells * 4); ENSURE(c, c->d_matD, c->mat_cells * 4);
+    ENSURE(c, c->d_cov, c->sum_bb * 4); ENSURE(c, c->d_bvote, c->sum_bb * 4);
+    ENSURE(c, c->d_cns_off, (size_t)T * 8); ENSURE(c, c->d_cns_len, T4);
+    ENSURE(c, c->d_seg_first, (size_t)T * 8); ENSURE(c, c->d_n_seg, T4);
+
+    // first guesses for the data-dependent arenas; a run that finds them too
+    // small records the exact need on the device and is repeated once.
+    c->norm_cap = std::max<uint64_t>(c->norm_cap, c->sum_len + c->sum_len / 32 + 8ull * c->A + 1024);
+    c->node_cap = std::max<uint64_t>(c->node_cap, c->sum_bb + c->sum_len / 7 + 1024);
+    c->pool_cap = std::max<uint64_t>(c->pool_cap, 22ull * c->node_cap);
+    c->cns_cap = std::max<uint64_t>(c->cns_cap, c->sum_bb + c->sum_bb / 4 + 1024);
+    c->seg_cap = std::max<uint64_t>(c->seg_cap, (uint64_t)T * 4 + 1024);
+    if ((r = ensure_arenas(c))) return r;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->uploaded = true;
+    c->tm.reruns = 0;
+    return DAGCON_OK;
+}
+
+int dagcon_run(dagcon_ctx *ctx) {
+    if (!ctx) return DAGCON_ERR_INVALID_ARG;
+    Ctx *c = reinterpret_cast<Ctx *>(ctx);
+    if (!c->uploaded) return fail(c, DAGCON_ERR_STATE, "dagcon_run before dagcon_upload");
+    HIPCHK(c, hipSetDevice(c->device));
+    int r = launch_all(c);
+    if (r != DAGCON_OK) return r;
+    c->ran = true; c->fetched = false;
+    return DAGCON_OK;
+}
+
+int dagcon_sync(dagcon_ctx *ctx) {
+    if (!ctx) return DAGCON_ERR_INVALID_ARG;
+    Ctx *c = reinterpret_cast<Ctx *>(ctx);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return DAGCON_OK;
+}
+
+static int read_status(Ctx *c) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(&c->h_st, c->d_st.p, sizeof(DgStatus), hipMemcpyDeviceToHost));
+    return DAGCON_OK;
+}
+
+int dagcon_fetch(dagcon_ctx *ctx, dagcon_results *res) {
+    if (!ctx || !res) return DAGCON_ERR_INVALID_ARG;
+    Ctx *c = reinterpret_cast<Ctx *>(ctx);
+    if (!c->ran) return fail(c, DAGCON_ERR_STATE, "dagcon_fetch before dagcon_run");
+    HIPCHK(c, hipSetDevice(c->device));
+    int r;
+    for (int attempt = 0;; attempt++) {
+        if ((r = read_status(c))) return r;
+        const uint32_t f = c->h_st.err_flags;
+        if (f == 0) break;
+        if (f & DG_E_BADCHAR)
+            return fail(c, DAGCON_ERR_NONCONFORMING, "alignment %u holds a byte outside printable ASCII", c->h_st.bad_aln);
+        if (f & DG_E_NONCONF)
+            return fail(c, DAGCON_ERR_NONCONFORMING,
+                        "alignment %u (after the min_len filter) leaves the backbone: start < 1 or target bases past tlen",
+                        c->h_st.bad_aln);
+        if (f & DG_E_INTERNAL)
+            return fail(c, DAGCON_ERR_INTERNAL, "device invariant violated in target %u", c->h_st.bad_target);
+        if (attempt >= 6) return fail(c, DAGCON_ERR_WORKSPACE, "workspace still too small after %d re-runs (flags 0x%x)", attempt, f);
+        if (f & DG_E_NORM_OVF) c->norm_cap = c->h_st.norm_top + 1024;
+        if (f & DG_E_NODE_OVF) c->node_cap = c->h_st.node_need + 1024;
+        if (f & DG_E_POOL_OVF) c->pool_cap = c->h_st.pool_need + 1024;
+        if (f & DG_E_POOL_TGT) c->growth_pct *= 3;
+        if (f & DG_E_STACK) c->stk_words *= 4;
+        if (f & DG_E_OUT_OVF) {
+            c->cns_cap = std::max<uint64_t>(c->cns_cap, c->h_st.cns_top + 1024);
+            c->seg_cap = std::max<uint64_t>(c->seg_cap, c->h_st.seg_top + 1024);
+        }
+        c->tm.reruns++;
+        if ((r = launch_all(c))) return r;
+    }
+    // timings
+    float ms = 0;
+    HIPCHK(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[4])); c->tm.ms_total = ms;
+    HIPCHK(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1])); c->tm.ms_normalize = ms;
+    HIPCHK(c, hipEventElapsedTime(&ms, c->ev[1], c->ev[2])); c->tm.ms_build = ms;
+    HIPCHK(c, hipEventElapsedTime(&ms, c->ev[2], c->ev[3])); c->tm.ms_merge = ms;
+    HIPCHK(c, hipEventElapsedTime(&ms, c->ev[3], c->ev[4])); c->tm.ms_bestpath = ms;
+
+    const uint32_t T = c->T;
+    const uint64_t nseg = c->h_st.seg_top, nb = c->h_st.cns_top;
+    c->r_cns_off.assign(T, 0); c->r_cns_len.assign(T, 0); c->r_seg_first.assign(T, 0); c->r_n_seg.assign(T, 0);
+    c->r_tmp0.assign(nseg, 0); c->r_tmp1.assign(nseg, 0);
+    c->r_blob.assign(nb + 1, 0);
+    const bool full = !(c->opts.flags & (DAGCON_FLAG_STOP_AFTER_BUILD | DAGCON_FLAG_STOP_AFTER_MERGE));
+    if (T && full) {
+        HIPCHK(c, hipMemcpy(c->r_cns_off.data(), c->d_cns_off.p, (size_t)T * 8, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(c->r_cns_len.data(), c->d_cns_len.p, (size_t)T * 4, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(c->r_seg_first.data(), c->d_seg_first.p, (size_t)T * 8, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(c->r_n_seg.data(), c->d_n_seg.p, (size_t)T * 4, hipMemcpyDeviceToHost));
+        if (nseg) {
+            HIPCHK(c, hipMemcpy(c->r_tmp0.data(), c->d_seg_r0.p, nseg * 4, hipMemcpyDeviceToHost));
+            HIPCHK(c, hipMemcpy(c->r_tmp1.data(), c->d_seg_r1.p, nseg * 4, hipMemcpyDeviceToHost));
+        }
+        if (nb) HIPCHK(c, hipMemcpy(c->r_blob.data(), c->d_cns.p, nb, hipMemcpyDeviceToHost));
+    }
+    c->r_seg_begin.assign(T + 1, 0);
+    c->r_range0.clear(); c->r_range1.clear(); c->r_seq_off.clear(); c->r_seq_len.clear();
+    uint64_t bases = 0;
+    for (uint32_t t = 0; t < T; t++) {
+        c->r_seg_begin[t] = c->r_range0.size();
+        if (!full || !c->h_tactive[t]) continue;
+        for (uint32_t i = 0; i < c->r_n_seg[t]; i++) {
+            const uint64_t s = c->r_seg_first[t] + i;
+            const int32_t r0 = c->r_tmp0[s], r1 = c->r_tmp1[s];
+            c->r_range0.push_back(r0); c->r_range1.push_back(r1);
+            c->r_seq_off.push_back(c->r_cns_off[t] + (uint64_t)r0);
+            c->r_seq_len.push_back((uint32_t)(r1 - r0));
+            bases += (uint64_t)(r1 - r0);
+        }
+    }
+    c->r_seg_begin[T] = c->r_range0.size();
+    c->tm.consensus_bases = bases;
+    c->tm.algorithmic_bytes = 2ull * c->sum_len + bases;
+    c->tm.n_alignments = c->A;
+    c->tm.n_columns = c->h_st.n_columns;
+    c->tm.n_nodes = c->h_st.node_need;
+    res->n_targets = T;
+    res->n_segments = c->r_range0.size();
+    res->seg_begin = c->r_seg_begin.data();
+    res->range0 = c->r_range0.data(); res->range1 = c->r_range1.data();
+    res->seq_off = c->r_seq_off.data(); res->seq_len = c->r_seq_len.data();
+    res->seq_blob = c->r_blob.data(); res->seq_bytes = nb;
+    c->fetched = true;
+    return DAGCON_OK;
+}
+
+int dagcon_get_timings(dagcon_ctx *ctx, dagcon_timings *out) {
+    if (!ctx || !out) return DAGCON_ERR_INVALID_ARG;
+    Ctx *c = reinterpret_cast<Ctx *>(ctx);
+    if (!c->ran) return fail(c, DAGCON_ERR_STATE, "no run to report");
+    if (!c->fetched) {
+        // timings of a run that has been synchronised but not fetched
+        HIPCHK(c, hipSetDevice(c->device));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        float ms = 0;
+        HIPCHK(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[4])); c->tm.ms_total = ms;
+        HIPCHK(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1])); c->tm.ms_normalize = ms;
+        HIPCHK(c, hipEventElapsedTime(&ms, c->ev[1], c->ev[2])); c->tm.ms_build = ms;
+        HIPCHK(c, hipEventElapsedTime(&ms, c->ev[2], c->ev[3])); c->tm.ms_merge = ms;
+        HIPCHK(c, hipEventElapsedTime(&ms, c->ev[3], c->ev[4])); c->tm.ms_bestpath = ms;
+    }
+    *out = c->tm;
+    return DAGCON_OK;
+}
+
+int dagcon_consensus(dagcon_ctx *ctx, const dagcon_batch *batch, dagcon_results *results) {
+    int r = dagcon_upload(ctx, batch);
+    if (r != DAGCON_OK) return r;
+    if ((r = dagcon_run(ctx)) != DAGCON_OK) return r;
+    return dagcon_fetch(ctx, results);
+}
+
+static int normalize_impl(Ctx *c, dagcon_ctx *ctx, uint32_t n, const uint32_t *aln_start,
+                          const uint64_t *aln_off, const uint32_t *aln_len, const char *qstr,
+                          const char *tstr, uint64_t blob_bytes, const uint64_t *out_off, char *qout,
+                          char *tout, uint32_t *out_len, uint32_t *out_start) {
+    // one pseudo target (tlen 0) that holds every alignment; only the a1
+    // kernels run, with the graph stage's conformity check switched off
+    std::vector<uint32_t> tl(1, 0u);
+    std::vector<uint64_t> ab = {0, n};
+    dagcon_batch b;
+    memset(&b, 0, sizeof b);
+    b.n_targets = 1; b.tlen = tl.data(); b.aln_begin = ab.data();
+    b.aln_start = aln_start; b.aln_off = aln_off; b.aln_len = aln_len;
+    b.qstr = qstr; b.tstr = tstr; b.blob_bytes = blob_bytes;
+    int r = dagcon_upload(ctx, &b);
+    if (r != DAGCON_OK) return r;
+    for (int attempt = 0;; attempt++) {
+        DgParams p;
+        fill_params(c, p);
+        p.flags |= DG_F_A1_ONLY;
+        HIPCHK(c, hipMemsetAsync(c->d_st.p, 0, sizeof(DgStatus), c->stream));
+        if (c->A) {
+            hipLaunchKernelGGL(k_count, dim3(c->A), dim3(256), 0, c->stream, p);
+            hipLaunchKernelGGL(k_normalize, dim3((c->A + 63) / 64), dim3(64), 0, c->stream, p);
+        }
+        HIPCHK(c, hipGetLastError());
+        if ((r = read_status(c))) return r;
+        if ((c->h_st.err_flags & DG_E_NORM_OVF) && attempt < 3) {
+            c->norm_cap = c->h_st.norm_top + 1024;
+            if ((r = ensure_arenas(c))) return r;
+            continue;
+        }
+        break;
+    }
+    if (c->h_st.err_flags & DG_E_BADCHAR)
+        return fail(c, DAGCON_ERR_NONCONFORMING, "alignment %u holds a byte outside printable ASCII", c->h_st.bad_aln);
+    if (c->h_st.err_flags) return fail(c, DAGCON_ERR_INTERNAL, "normalize failed (flags 0x%x)", c->h_st.err_flags);
+    std::vector<uint64_t> noff(n);
+    std::vector<uint32_t> lo(n), hi(n), st(n);
+    if (n) {
+        HIPCHK(c, hipMemcpy(noff.data(), c->d_norm_off.p, (size_t)n * 8, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(lo.data(), c->d_n_lo.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(hi.data(), c->d_n_hi.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(st.data(), c->d_n_start.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    }
+    std::vector<uint16_t> cols;
+    for (uint32_t a = 0; a < n; a++) {
+        const uint32_t m = hi[a] - lo[a];
+        cols.resize(m);
+        if (m) HIPCHK(c, hipMemcpy(cols.data(), (const uint16_t *)c->d_norm.p + noff[a] + lo[a], (size_t)m * 2, hipMemcpyDeviceToHost));
+        for (uint32_t i = 0; i < m; i++) {
+            qout[out_off[a] + i] = (char)(cols[i] & 0xff);
+            tout[out_off[a] + i] = (char)(cols[i] >> 8);
+        }
+        out_len[a] = m;
+        out_start[a] = st[a];
+    }
+    return DAGCON_OK;
+}
+
+int dagcon_normalize(dagcon_ctx *ctx, uint32_t n, const uint32_t *aln_start, const uint64_t *aln_off,
+                     const uint32_t *aln_len, const char *qstr, const char *tstr, uint64_t blob_bytes,
+                     uint32_t trim, uint32_t flags, const uint64_t *out_off, char *qout, char *tout,
+                     uint32_t *out_len, uint32_t *out_start) {
+    if (!ctx) return DAGCON_ERR_INVALID_ARG;
+    Ctx *c = reinterpret_cast<Ctx *>(ctx);
+    if (n && (!aln_start || !aln_off || !aln_len || !qstr || !tstr || !out_off || !qout || !tout || !out_len || !out_start))
+        return fail(c, DAGCON_ERR_INVALID_ARG, "NULL argument");
+    if (n > DAGCON_MAX_COVERAGE)
+        return fail(c, DAGCON_ERR_UNSUPPORTED, "dagcon_normalize takes at most %u alignments per call", DAGCON_MAX_COVERAGE);
+    const dagcon_opts saved = c->opts;
+    c->opts.min_cov = 0; c->opts.min_len = 0; c->opts.trim = trim;
+    c->opts.flags = flags & DAGCON_FLAG_RAW_ALIGNMENTS;
+    const int r = normalize_impl(c, ctx, n, aln_start, aln_off, aln_len, qstr, tstr, blob_bytes, out_off,
+                                 qout, tout, out_len, out_start);
+    c->opts = saved;
+    c->uploaded = false; c->ran = false;
+    return r;
+}
+
+int dagcon_debug_graph(dagcon_ctx *ctx, uint32_t target, dagcon_graph_dump *out) {
+    if (!ctx || !out) return DAGCON_ERR_INVALID_ARG;
+    Ctx *c = reinterpret_cast<Ctx *>(ctx);
+    if (!c->ran) return fail(c, DAGCON_ERR_STATE, "dagcon_debug_graph before dagcon_run");
+    if (target >= c->T) return fail(c, DAGCON_ERR_INVALID_ARG, "target out of range");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    uint64_t nb = 0, pb = 0;
+    uint32_t N = 0, psz = 0;
+    HIPCHK(c, hipMemcpy(&nb, (uint64_t *)c->d_node_base.p + target, 8, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(&pb, (uint64_t *)c->d_pool_base.p + target, 8, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(&N, (uint32_t *)c->d_n_nodes.p + target, 4, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(&psz, (uint32_t *)c->d_pool_top.p + target, 4, hipMemcpyDeviceToHost));
+    if (!c->h_tactive[target]) N = 0;
+    std::vector<DgHot> hot(N);
+    std::vector<DgLists> ls(N);
+    std::vector<uint32_t> pool(psz);
+    c->g_weight.assign(N, 0); c->g_cov.assign(N, 0);
+    if (N) {
+        HIPCHK(c, hipMemcpy(hot.data(), (DgHot *)c->d_hot.p + nb, (size_t)N * sizeof(DgHot), hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(ls.data(), (DgLists *)c->d_lists.p + nb, (size_t)N * sizeof(DgLists), hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(c->g_weight.data(), (int32_t *)c->d_weight.p + nb, (size_t)N * 4, hipMemcpyDeviceToHost));
+        const uint32_t nbb = c->h_tlen[target] + 2;
+        HIPCHK(c, hipMemcpy(c->g_cov.data(), (int32_t *)c->d_cov.p + c->h_bbv_base[target], (size_t)nbb * 4, hipMemcpyDeviceToHost));
+        if (psz) HIPCHK(c, hipMemcpy(pool.data(), (uint32_t *)c->d_pool.p + pb, (size_t)psz * 4, hipMemcpyDeviceToHost));
+    }
+    c->g_base.assign(N, 0); c->g_deleted.assign(N, 0);
+    c->g_out_begin.assign(N + 1, 0); c->g_in_begin.assign(N + 1, 0);
+    c->g_out_dst.clear(); c->g_out_cnt.clear(); c->g_in_src.clear();
+    for (uint32_t v = 0; v < N; v++) {
+        c->g_base[v] = hot[v].base;
+        c->g_deleted[v] = (hot[v].flags & DG_NF_DELETED) ? 1 : 0;
+        c->g_out_begin[v] = (uint32_t)c->g_out_dst.size();
+        c->g_in_begin[v] = (uint32_t)c->g_in_src.size();
+        for (uint32_t i = 0; i < hot[v].out_len; i++) {
+            c->g_out_dst.push_back((int32_t)pool[ls[v].out_off + 2 * i]);
+            c->g_out_cnt.push_back((int32_t)pool[ls[v].out_off + 2 * i + 1]);
+        }
+        for (uint32_t i = 0; i < hot[v].in_len; i++) c->g_in_src.push_back((int32_t)pool[ls[v].in_off + i]);
+    }
+    c->g_out_begin[N] = (uint32_t)c->g_out_dst.size();
+    c->g_in_begin[N] = (uint32_t)c->g_in_src.size();
+    out->n_nodes = N;
+    out->base = c->g_base.data(); out->weight = c->g_weight.data(); out->coverage = c->g_cov.data();
+    out->deleted = c->g_deleted.data();
+    out->out_begin = c->g_out_begin.data(); out->out_dst = c->g_out_dst.data(); out->out_count = c->g_out_cnt.data();
+    out->in_begin = c->g_in_begin.data(); out->in_src = c->g_in_src.data();
+    return DAGCON_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,443 @@
+// k_build.hip.h -- stage (a): alignment strings -> alignment DAG in HBM.
+//
+//   k_count      a1  mismatch count per alignment (sizes the column buffer), byte validation
+//   k_normalize  a1  normalizeGaps (Alignment.cpp:131-217) + trimAln (:219-242), one lane per alignment
+//   k_carve      a2  exact vertex / pool needs per target, exclusive scans -> arena offsets
+//   k_init_nodes a2  backbone vertices (AlnGraphBoost.cpp:16-62)
+//   k_emit       a2  addAln (AlnGraphBoost.cpp:64-107): one lane per alignment walks its columns
+//   k_lists      a2  addEdge dedupe (AlnGraphBoost.cpp:109-127): one wave per backbone vertex turns
+//                    its arrival / departure row into ordered adjacency lists (ballot / popcount)
+#pragma once
+#include <hip/hip_runtime.h>
+#include "dagcon_dev.h"
+
+#define DG_WAVE 64
+
+__device__ __forceinline__ bool dg_failed(const DgParams &p) {
+    return __hip_atomic_load(&p.st->err_flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+}
+__device__ __forceinline__ void dg_fail(const DgParams &p, uint32_t bit) {
+    atomicOr(&p.st->err_flags, bit);
+}
+
+// ---------------------------------------------------------------------------
+// k_count: one 256-thread block per alignment.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_count(DgParams p) {
+    const uint32_t a = blockIdx.x;
+    if (a >= p.A) return;
+    const uint64_t off = p.aln_off[a];
+    const uint32_t len = p.aln_len[a];
+    const uint8_t *q = p.q + off, *t = p.t + off;
+    uint32_t mis = 0, bad = 0;
+    for (uint32_t i = threadIdx.x; i < len; i += 256) {
+        uint8_t qb = q[i], tb = t[i];
+        bad |= (qb < 33 || qb > 126 || tb < 33 || tb > 126);
+        if (qb == '.') qb = DG_GAP;
+        if (tb == '.') tb = DG_GAP;
+        mis += (qb != tb && qb != DG_GAP && tb != DG_GAP);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        mis += __shfl_down(mis, o);
+        bad |= __shfl_down(bad, o);
+    }
+    __shared__ uint32_t s_mis[4], s_bad[4];
+    if ((threadIdx.x & 63) == 0) { s_mis[threadIdx.x >> 6] = mis; s_bad[threadIdx.x >> 6] = bad; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        mis = s_mis[0] + s_mis[1] + s_mis[2] + s_mis[3];
+        bad = s_bad[0] | s_bad[1] | s_bad[2] | s_bad[3];
+        if (p.flags & 1u) mis = 0;   // raw mode: columns are taken as they are
+        if (bad) { dg_fail(p, DG_E_BADCHAR); p.st->bad_aln = a; }
+        p.nmis[a] = mis;
+        unsigned long long cap = ((unsigned long long)len + mis + 7ull) & ~7ull;
+        unsigned long long o = atomicAdd(&p.st->norm_top, cap);
+        p.norm_off[a] = o;
+        if (o + cap > p.norm_cap) dg_fail(p, DG_E_NORM_OVF);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k_normalize: one lane per alignment; sequential by nature (gap pushing is a
+// left-to-right rewrite with unbounded look-ahead), parallel over alignments.
+// Columns are uint16: low byte = query char, high byte = target char.
+// ---------------------------------------------------------------------------
+#define DG_COL(qb, tb) ((uint16_t)((uint16_t)(qb) | ((uint16_t)(tb) << 8)))
+#define DG_Q(c) ((uint8_t)((c) & 0xff))
+#define DG_T(c) ((uint8_t)((c) >> 8))
+
+__global__ __launch_bounds__(64) void k_normalize(DgParams p) {
+    const uint32_t a = blockIdx.x * 64 + threadIdx.x;
+    if (a >= p.A) return;
+    if (dg_failed(p)) return;
+    const uint64_t off = p.aln_off[a];
+    const uint32_t len = p.aln_len[a];
+    const uint8_t *q = p.q + off, *t = p.t + off;
+    uint16_t *buf = p.norm + p.norm_off[a];
+    const bool raw = (p.flags & 1u) != 0;
+
+    // Alignment.cpp:142-159: dots to dashes, mismatches to a deletion + an insertion
+    uint32_t n = 0;
+    for (uint32_t i = 0; i < len; i++) {
+        uint8_t qb = q[i], tb = t[i];
+        if (!raw) {
+            if (qb == '.') qb = DG_GAP;
+            if (tb == '.') tb = DG_GAP;
+            if (qb != tb && qb != DG_GAP && tb != DG_GAP) {
+                buf[n++] = DG_COL(DG_GAP, tb);
+                buf[n++] = DG_COL(qb, DG_GAP);
+                continue;
+            }
+        }
+        buf[n++] = DG_COL(qb, tb);
+    }
+
+    uint32_t m = n;      // final column count
+    uint32_t lo = 0, hi = n;
+    uint32_t start = p.aln_start[a];
+    if (!raw) {
+        // Alignment.cpp:165-198: push gaps to the right.  jt / jq are the
+        // look-ahead cursors of the two inner while loops; they only move
+        // forward (a column left of the cursor is never turned back into a
+        // base), so the whole pass is O(n).  Column i is final once the loop
+        // has passed it, so the all-gap filter of :209-214 is fused in.
+        uint32_t w = 0, jt = 0, jq = 0;
+        for (uint32_t i = 0; i < n; i++) {
+            uint16_t c = buf[i];
+            uint8_t qi = DG_Q(c), ti = DG_T(c);
+            if (i + 1 < n) {
+                if (ti == DG_GAP) {
+                    if (jt <= i) jt = i + 1;
+                    while (jt < n && DG_T(buf[jt]) == DG_GAP) jt++;
+                    if (jt < n) {
+                        uint16_t cj = buf[jt];
+                        if (DG_T(cj) == qi) {
+                            ti = qi;
+                            buf[jt] = DG_COL(DG_Q(cj), DG_GAP);
+                        }
+                    }
+                }
+                if (qi == DG_GAP) {
+                    if (jq <= i) jq = i + 1;
+                    while (jq < n && DG_Q(buf[jq]) == DG_GAP) jq++;
+                    if (jq < n) {
+                        uint16_t cj = buf[jq];
+                        if (DG_Q(cj) == ti) {
+                            qi = ti;
+                            buf[jq] = DG_COL(DG_GAP, DG_T(cj));
+                        }
+                    }
+                }
+            }
+            if (qi != DG_GAP || ti != DG_GAP) buf[w++] = DG_COL(qi, ti);
+        }
+        m = w;
+    }
+    {
+        // Alignment.cpp:219-242 trimAln (a no-op for trim == 0)
+        const uint32_t trim = p.trim;
+        uint32_t lbases = 0, rbases = 0;
+        lo = 0; hi = m;
+        while (lbases < trim && lo < m) {
+            if (DG_T(buf[lo++]) != DG_GAP) lbases++;
+        }
+        while (rbases < trim && hi > lo) {
+            if (DG_T(buf[--hi]) != DG_GAP) rbases++;
+        }
+        start += lbases;
+    }
+
+    // what addAln will do with the window: insertions create vertices,
+    // matches and deletions advance the backbone cursor (AlnGraphBoost.cpp:75-104)
+    uint32_t n_ins = 0, n_del = 0, adv = 0;
+    for (uint32_t i = lo; i < hi; i++) {
+        uint16_t c = buf[i];
+        uint8_t qb = DG_Q(c), tb = DG_T(c);
+        if (qb == tb) adv++;
+        else if (qb == DG_GAP) { adv++; n_del++; }
+        else if (tb == DG_GAP) n_ins++;
+    }
+    p.n_lo[a] = lo; p.n_hi[a] = hi; p.n_start[a] = start;
+    p.n_ins[a] = n_ins; p.n_del[a] = n_del;
+    const uint32_t tlen = p.tlen[p.aln_tgt[a]];
+    if (!(p.flags & DG_F_A1_ONLY) && hi > lo && (start < 1 || (uint64_t)start - 1 + adv > (uint64_t)tlen)) {
+        dg_fail(p, DG_E_NONCONF);
+        p.st->bad_aln = a;
+    }
+    atomicAdd(&p.st->n_columns, (unsigned long long)(hi - lo));
+}
+
+// ---------------------------------------------------------------------------
+// k_carve: a single 1024-thread block.  Exact sizes per target, then
+// exclusive scans over targets for the arena offsets.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t dg_pool_words(uint32_t tlen, uint32_t n_ins, uint32_t n_del,
+                                                  uint32_t k, uint32_t growth_pct, uint32_t *ins_words) {
+    // backbone lists: every list has the constructor edge plus at most one
+    // entry per insertion run / deletion run / read end that touches it;
+    // 2 spare slots per list.  out entries take 2 words, in entries 1.
+    uint64_t bb_entries = (uint64_t)(tlen + 2) * 3ull + n_ins + n_del + 2ull * k;
+    uint64_t bb_words = 3ull * bb_entries;
+    uint64_t iw = 3ull * n_ins;
+    uint64_t growth = ((bb_words + iw) * growth_pct) / 100ull + 256ull;
+    *ins_words = (uint32_t)iw;
+    uint64_t tot = bb_words + iw + growth;
+    return tot > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)tot;
+}
+
+__global__ __launch_bounds__(1024) void k_carve(DgParams p) {
+    __shared__ unsigned long long s_scan[1024];
+    __shared__ unsigned long long s_carry_nodes, s_carry_pool;
+    if (dg_failed(p)) return;
+    const uint32_t tid = threadIdx.x;
+    if (tid == 0) { s_carry_nodes = 0; s_carry_pool = 0; }
+    __syncthreads();
+    for (uint32_t t0 = 0; t0 < p.T; t0 += 1024) {
+        const uint32_t t = t0 + tid;
+        unsigned long long nodes = 0, poolw = 0;
+        uint32_t ins_words = 0;
+        if (t < p.T && p.tactive[t]) {
+            uint32_t ins = 0, del = 0;
+            const uint64_t b = p.aln_begin[t], e = p.aln_begin[t + 1];
+            for (uint64_t a = b; a < e; a++) {
+                p.ins_base[a] = ins;
+                ins += p.n_ins[a];
+                del += p.n_del[a];
+            }
+            nodes = (unsigned long long)p.tlen[t] + 2ull + ins;
+            poolw = dg_pool_words(p.tlen[t], ins, del, (uint32_t)(e - b), p.growth_pct, &ins_words);
+        }
+        // block exclusive scan of nodes
+        s_scan[tid] = nodes;
+        __syncthreads();
+        for (uint32_t o = 1; o < 1024; o <<= 1) {
+            unsigned long long v = tid >= o ? s_scan[tid - o] : 0;
+            __syncthreads();
+            s_scan[tid] += v;
+            __syncthreads();
+        }
+        unsigned long long node_excl = s_scan[tid] - nodes + s_carry_nodes;
+        unsigned long long node_tot = s_scan[1023];
+        __syncthreads();
+        s_scan[tid] = poolw;
+        __syncthreads();
+        for (uint32_t o = 1; o < 1024; o <<= 1) {
+            unsigned long long v = tid >= o ? s_scan[tid - o] : 0;
+            __syncthreads();
+            s_scan[tid] += v;
+            __syncthreads();
+        }
+        unsigned long long pool_excl = s_scan[tid] - poolw + s_carry_pool;
+        unsigned long long pool_tot = s_scan[1023];
+        __syncthreads();
+        if (t < p.T) {
+            p.node_base[t] = node_excl;
+            p.n_nodes[t] = (uint32_t)nodes;
+            p.pool_base[t] = pool_excl;
+            p.pool_size[t] = (uint32_t)poolw;
+            p.pool_top[t] = ins_words;      // inserted vertices own the first 3*n_ins words
+        }
+        if (tid == 0) { s_carry_nodes += node_tot; s_carry_pool += pool_tot; }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        p.st->node_need = s_carry_nodes;
+        p.st->pool_need = s_carry_pool;
+        if (s_carry_nodes > p.node_cap) dg_fail(p, DG_E_NODE_OVF);
+        if (s_carry_pool > p.pool_cap) dg_fail(p, DG_E_POOL_OVF);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k_init_nodes: grid (T, chunks of 256 backbone vertices).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_init_nodes(DgParams p) {
+    const uint32_t t = blockIdx.x;
+    if (dg_failed(p) || !p.tactive[t]) return;
+    const uint32_t blen = p.tlen[t];
+    const uint32_t v = blockIdx.y * 256 + threadIdx.x;
+    if (v >= blen + 2) return;
+    const uint64_t nb = p.node_base[t];
+    DgHot h;
+    h.out_len = 0; h.in_len = 0; h.flags = DG_NF_BACKBONE; h.pad = 0;
+    if (v == 0) h.base = '^';
+    else if (v == blen + 1) h.base = '$';
+    else h.base = p.bb ? p.bb[p.bb_off[t] + (v - 1)] : (uint8_t)'N';
+    p.hot[nb + v] = h;
+    const bool inner = (v >= 1 && v <= blen);
+    p.weight[nb + v] = inner ? 1 : 0;
+    p.bbpos[nb + v] = inner ? (int32_t)v : 0;   // _bbMap: absent key (enter, exit) reads as 0
+    const uint64_t bv = p.bbv_base[t] + v;
+    p.cov[bv] = 0;
+    p.bvote[bv] = 0;
+}
+
+// ---------------------------------------------------------------------------
+// k_emit: addAln, one lane per alignment.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_emit(DgParams p) {
+    const uint32_t a = blockIdx.x * 64 + threadIdx.x;
+    if (a >= p.A) return;
+    if (dg_failed(p)) return;
+    const uint32_t t = p.aln_tgt[a];
+    if (!p.tactive[t]) return;
+    const uint64_t ab = p.aln_begin[t];
+    const uint32_t r = (uint32_t)(a - ab);
+    const uint32_t K = (uint32_t)(p.aln_begin[t + 1] - ab);
+    const uint32_t blen = p.tlen[t];
+    const uint32_t exitv = blen + 1;
+    const uint64_t nb = p.node_base[t];
+    const uint64_t bv = p.bbv_base[t];
+    uint32_t *Am = p.matA + p.mat_base[t];
+    uint32_t *Dm = p.matD + p.mat_base[t];
+    uint32_t *pool = p.pool + p.pool_base[t];
+    const uint32_t n_ins_t = p.pool_top[t] / 3u;   // carve left 3*n_ins here; k_lists bumps it later
+    const uint16_t *buf = p.norm + p.norm_off[a];
+    const uint32_t lo = p.n_lo[a], hi = p.n_hi[a];
+    uint32_t bbpos = p.n_start[a];
+    uint32_t prev = 0;
+    uint32_t ins_idx = p.ins_base[a];     // index among the target's inserted vertices
+
+#define DG_DEPART(PREV, NXT)                                              \
+    do {                                                                  \
+        if ((PREV) < blen + 2) Dm[(uint64_t)(PREV) * K + r] = (NXT) + 1u; \
+        else {                                                            \
+            uint32_t _i = (PREV) - (blen + 2);                            \
+            pool[2u * _i] = (NXT);                                        \
+            pool[2u * _i + 1u] = 1u;                                      \
+        }                                                                 \
+    } while (0)
+
+    for (uint32_t i = lo; i < hi; i++) {
+        const uint16_t c = buf[i];
+        const uint8_t qb = DG_Q(c), tb = DG_T(c);
+        if (qb == tb) {                                   // match  (AlnGraphBoost.cpp:75-85)
+            atomicAdd(&p.cov[bv + bbpos], 1);
+            atomicMax(&p.bvote[bv + bbpos], ((r + 1u) << 8) | tb);
+            atomicAdd(&p.weight[nb + bbpos], 1);
+            Am[(uint64_t)bbpos * K + r] = prev + 1u;
+            DG_DEPART(prev, bbpos);
+            prev = bbpos;
+            bbpos++;
+        } else if (qb == DG_GAP) {                        // deletion (:87-93)
+            atomicAdd(&p.cov[bv + bbpos], 1);
+            atomicMax(&p.bvote[bv + bbpos], ((r + 1u) << 8) | tb);
+            bbpos++;
+        } else if (tb == DG_GAP) {                        // insertion (:95-104)
+            const uint32_t id = blen + 2 + ins_idx;
+            DgHot h;
+            h.out_len = 1; h.in_len = 1; h.base = qb; h.flags = 0; h.pad = 0;
+            p.hot[nb + id] = h;
+            DgLists l;
+            l.out_off = 2u * ins_idx; l.in_off = 2u * n_ins_t + ins_idx;
+            l.out_cap = 1; l.in_cap = 1; l.pad = 0;
+            p.lists[nb + id] = l;
+            p.weight[nb + id] = 1;
+            p.bbpos[nb + id] = (int32_t)bbpos;
+            p.pending[nb + id] = 1;
+            pool[2u * n_ins_t + ins_idx] = prev;
+            DG_DEPART(prev, id);
+            prev = id;
+            ins_idx++;
+        }
+    }
+    Am[(uint64_t)exitv * K + r] = prev + 1u;              // :106
+    DG_DEPART(prev, exitv);
+#undef DG_DEPART
+}
+
+// ---------------------------------------------------------------------------
+// k_lists: one wave per backbone vertex.  Row of K departures -> out list
+// [ (v+1, n) , then distinct other targets in first-read order with counts ];
+// row of K arrivals -> in list [ v-1, then distinct other sources ].
+// Distinct values are peeled off with ballot/popcount; the list under
+// construction sits in LDS so that rows longer than one wave still dedupe.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int dg_lds_find(volatile int32_t *vals, int n, int x, int lane) {
+    for (int b = 0; b < n; b += DG_WAVE) {
+        int i = b + lane;
+        bool hit = (i < n) && (vals[i] == x);
+        unsigned long long m = __ballot(hit);
+        if (m) return b + (__ffsll((long long)m) - 1);
+    }
+    return -1;
+}
+
+__device__ __forceinline__ uint32_t dg_pool_alloc(const DgParams &p, uint32_t t, uint32_t words, int lane) {
+    uint32_t off = 0;
+    if (lane == 0) {
+        off = atomicAdd(&p.pool_top[t], words);
+        if ((uint64_t)off + words > p.pool_size[t]) { dg_fail(p, DG_E_POOL_TGT); p.st->bad_target = t; off = 0xFFFFFFFFu; }
+    }
+    return __shfl(off, 0);
+}
+
+__global__ __launch_bounds__(256) void k_lists(DgParams p) {
+    extern __shared__ int32_t s_tmp[];      // per wave: vals[max_k+2], cnts[max_k+2]
+    const uint32_t t = blockIdx.x;
+    if (dg_failed(p) || !p.tactive[t]) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t blen = p.tlen[t];
+    const uint32_t v = blockIdx.y * 4 + wave;
+    if (v >= blen + 2) return;
+    const uint32_t K = (uint32_t)(p.aln_begin[t + 1] - p.aln_begin[t]);
+    const uint32_t stride = p.max_k + 2;
+    volatile int32_t *vals = s_tmp + (size_t)wave * 2 * stride;
+    volatile int32_t *cnts = vals + stride;
+    const uint64_t nb = p.node_base[t];
+    uint32_t *pool = p.pool + p.pool_base[t];
+    const uint32_t *Am = p.matA + p.mat_base[t] + (uint64_t)v * K;
+    const uint32_t *Dm = p.matD + p.mat_base[t] + (uint64_t)v * K;
+    DgLists l;
+    l.out_off = 0; l.in_off = 0; l.out_cap = 0; l.in_cap = 0; l.pad = 0;
+    uint32_t out_len = 0, in_len = 0;
+
+    for (int dir = 0; dir < 2; dir++) {
+        // dir 0: out list from departures; dir 1: in list from arrivals
+        if (dir == 0 && v == blen + 1) continue;
+        if (dir == 1 && v == 0) continue;
+        const uint32_t *row = dir == 0 ? Dm : Am;
+        int n = 1;
+        if (lane == 0) { vals[0] = dir == 0 ? (int32_t)(v + 1) : (int32_t)(v - 1); cnts[0] = 0; }
+        for (uint32_t r0 = 0; r0 < K; r0 += DG_WAVE) {
+            const uint32_t r = r0 + lane;
+            const int32_t val = r < K ? (int32_t)row[r] : 0;      // neighbour id + 1, 0 = none
+            unsigned long long rem = __ballot(val != 0);
+            while (rem) {
+                const int first = __ffsll((long long)rem) - 1;
+                const int32_t x = __shfl(val, first);
+                const unsigned long long same = __ballot(val == x);
+                rem &= ~same;
+                const int c = __popcll(same);
+                const int idx = dg_lds_find(vals, n, x - 1, lane);
+                if (idx >= 0) {
+                    if (lane == 0) cnts[idx] += c;
+                } else {
+                    if (lane == 0) { vals[n] = x - 1; cnts[n] = c; }
+                    n++;
+                }
+            }
+        }
+        if (n > 65000) { if (lane == 0) dg_fail(p, DG_E_INTERNAL); return; }
+        const uint32_t cap = (uint32_t)n + 2u;
+        const uint32_t words = dir == 0 ? 2u * cap : cap;
+        const uint32_t off = dg_pool_alloc(p, t, words, lane);
+        if (off == 0xFFFFFFFFu) return;
+        for (int i = lane; i < n; i += DG_WAVE) {
+            if (dir == 0) { pool[off + 2 * i] = (uint32_t)vals[i]; pool[off + 2 * i + 1] = (uint32_t)cnts[i]; }
+            else pool[off + i] = (uint32_t)vals[i];
+        }
+        if (dir == 0) { l.out_off = off; l.out_cap = (uint16_t)cap; out_len = (uint32_t)n; }
+        else { l.in_off = off; l.in_cap = (uint16_t)cap; in_len = (uint32_t)n; }
+    }
+    if (lane == 0) {
+        DgHot h = p.hot[nb + v];
+        h.out_len = (uint16_t)out_len;
+        h.in_len = (uint16_t)in_len;
+        const uint32_t vote = p.bvote[p.bbv_base[t] + v];
+        if (vote) h.base = (uint8_t)(vote & 0xff);     // last read to cover the position wins
+        p.hot[nb + v] = h;
+        p.lists[nb + v] = l;
+        p.pending[nb + v] = (int32_t)in_len;
+    }
+}

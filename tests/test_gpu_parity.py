@@ -1,0 +1,239 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the CPU oracle.
+
+Integer / byte / index work: everything must be bit-exact.  The one floating
+point quantity (bestPath scores, fp32) only decides comparisons; its values
+are exact multiples of 0.5, so there is no tolerance anywhere in this file.
+"""
+import numpy as np
+import pytest
+
+import oracle
+from oracle import pymodel
+from pbdagcon_amd import capi, synth
+from pbdagcon_amd.consensus import Alignment, AlnGraphBoost, normalizeGaps, trimAln
+from util import batch_from_targets, oracle_batch, random_target
+
+pytestmark = pytest.mark.gpu
+
+
+# ---- reference KATs, through the device -------------------------------------
+
+def test_normalize_kat_device():
+    """test/cpp/AlignmentTest.cpp:19-47 + src/tests/test_aligngraph.py:50-54."""
+    for q, t, qe, te in [
+        (b"CAC", b"CGC", b"C-AC", b"CG-C"),
+        (b"-C--CGT", b"CCGAC-T", b"CCG--T", b"CCGACT"),
+        (b"ATAT-AGCCGGC", b"ATATTA---GGC", b"ATAT-AGCCGGC", b"ATATTAG--G-C"),
+        (b"CAACAT", b"C-A-AT", b"CAACAT", b"CAA--T"),
+    ]:
+        b = normalizeGaps(Alignment(start=1, qstr=q, tstr=t))
+        assert (b.qstr, b.tstr) == (qe, te)
+
+
+def test_trim_kat_device():
+    """test/cpp/AlignmentTest.cpp:80-143."""
+    t, q = b"ACG-TCA-GCA", b"AC-C-C-T---"
+    for trim, start, te, qe in [(0, 1, t, q), (3, 4, b"-TCA-", b"C-C-T"), (4, 5, b"C", b"C"),
+                                (5, 6, b"", b""), (500, None, b"", b"")]:
+        a = Alignment(start=1, qstr=q, tstr=t, strand="-")
+        trimAln(a, trim)
+        assert (a.tstr, a.qstr) == (te, qe)
+        if start is not None:
+            assert a.start == start
+
+
+def test_raw_consensus_kat_device():
+    """test/cpp/AlnGraphBoostTest.cpp:11-47: expected ATATAGCCGGC."""
+    ag = AlnGraphBoost(b"ATATTAGGC")
+    for t, q in [(b"ATATTA---GGC", b"ATAT-AGCCGGC"), (b"ATATTA-GGC", b"ATAT-ACGGC"),
+                 (b"AT-ATTA--GGC", b"ATCAT--CCGGC"), (b"ATATTA--G-GC", b"ATAT-ACCGAG-"),
+                 (b"ATATTA---GGC", b"ATAT-AGCCGGC")]:
+        ag.addAln(Alignment(id="target", tlen=9, start=1, qstr=q, tstr=t))
+    ag.mergeNodes()
+    assert ag.consensus() == b"ATATAGCCGGC"
+
+
+# ---- differential tests against the oracle -----------------------------------
+
+def _check_batch(ctx_factory, batch, min_cov=0, min_len=0, trim=0, min_weight=-1, graphs=()):
+    ctx = ctx_factory(min_cov=min_cov, min_len=min_len, trim=trim, min_weight=min_weight)
+    got = ctx.consensus(batch)
+    exp = oracle_batch(batch, min_cov, min_len, trim, min_weight)
+    assert len(got) == len(exp)
+    for t, (g, e) in enumerate(zip(got, exp)):
+        assert g == e, f"target {t}: consensus differs"
+    return ctx, got
+
+
+def _oracle_graph(batch, t, min_len, trim, merge):
+    g = oracle.Graph(blen=int(batch.tlen[t])) if batch.backbone is None else oracle.Graph(
+        backbone=batch.backbone[int(batch.backbone_off[t]):int(batch.backbone_off[t]) + int(batch.tlen[t])].tobytes())
+    for s, q, tt in batch.target_alignments(t):
+        if len(q) < min_len:
+            continue
+        qn, tn = oracle.normalize_gaps(q, tt)
+        qn, tn, s2 = oracle.trim_aln(qn, tn, s, trim)
+        g.add_aln(s2, qn, tn)
+    if merge:
+        assert g.merge_nodes() == 0
+    return [(b, w, c, d, oe, [s for s, _ in ie]) for b, w, c, d, oe, ie in g.adjacency()]
+
+
+@pytest.mark.parametrize("merge", [False, True])
+def test_graph_adjacency_matches_oracle(gpu_ctx_factory, merge):
+    """Stage a2 (and b) leave exactly the reference's graph: same vertices, same
+    weights / coverage / bases, same adjacency ORDER and edge counts."""
+    rng = np.random.default_rng(7)
+    targets = []
+    for i in range(24):
+        tl = int(rng.integers(5, 60))
+        alph = [b"ACGT", b"AC", b"A"][i % 3]
+        alns, bb = random_target(rng, tl, int(rng.integers(1, 9)), alphabet=alph, dots=(i % 5 == 0))
+        targets.append((tl, alns, bb))
+    batch = batch_from_targets(targets)
+    flags = capi.FLAG_STOP_AFTER_MERGE if merge else capi.FLAG_STOP_AFTER_BUILD
+    ctx = gpu_ctx_factory(min_cov=0, min_len=0, trim=2, min_weight=0, flags=flags)
+    ctx.consensus(batch)
+    for t in range(batch.n_targets):
+        got = ctx.debug_graph(t)
+        exp = _oracle_graph(batch, t, 0, 2, merge)
+        assert len(got) == len(exp), f"target {t}: vertex count"
+        for v, (g, e) in enumerate(zip(got, exp)):
+            gb, gw, gc, gd, goe, gie = g
+            eb, ew, ec, ed, eoe, eie = e
+            assert gd == ed, f"target {t} vertex {v}: deleted flag"
+            if ed:
+                continue
+            assert (gb, gw) == (eb, ew), f"target {t} vertex {v}: base/weight {g} vs {e}"
+            if v < int(batch.tlen[t]) + 2:
+                assert gc == ec, f"target {t} vertex {v}: coverage"
+            assert goe == eoe, f"target {t} vertex {v}: out list {goe} vs {eoe}"
+            assert gie == eie, f"target {t} vertex {v}: in list {gie} vs {eie}"
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_small_targets(gpu_ctx_factory, seed):
+    """Hundreds of adversarial little pileups: tiny alphabets, ragged spans, long
+    insertion runs, dots for gaps; several option settings."""
+    rng = np.random.default_rng(seed)
+    targets = []
+    for i in range(150):
+        tl = int(rng.integers(1, 120))
+        alph = [b"ACGT", b"AC", b"ACGTN", b"A"][i % 4]
+        alns, bb = random_target(rng, tl, int(rng.integers(0, 14)), alphabet=alph,
+                                 sub=float(rng.uniform(0, 0.1)), ins=float(rng.uniform(0, 0.3)),
+                                 dele=float(rng.uniform(0, 0.2)), dots=(i % 7 == 0),
+                                 full_span=(i % 3 == 0))
+        targets.append((tl, alns, bb))
+    batch = batch_from_targets(targets)
+    for kw in [dict(min_cov=0, min_len=0, trim=0, min_weight=0),
+               dict(min_cov=3, min_len=10, trim=3, min_weight=-1),
+               dict(min_cov=1, min_len=0, trim=1, min_weight=2)]:
+        _check_batch(gpu_ctx_factory, batch, **kw)
+
+
+def test_backbone_given_dazcon_style(gpu_ctx_factory):
+    """dazcon.cpp:76: real backbone bases (AlnGraphBoost.cpp:16-39)."""
+    rng = np.random.default_rng(11)
+    targets = []
+    for i in range(40):
+        tl = int(rng.integers(20, 200))
+        alns, bb = random_target(rng, tl, int(rng.integers(2, 10)), alphabet=b"ACGT")
+        targets.append((tl, alns, bb))
+    batch = batch_from_targets(targets, with_backbone=True)
+    _check_batch(gpu_ctx_factory, batch, min_cov=0, min_len=0, trim=1, min_weight=0)
+    _check_batch(gpu_ctx_factory, batch, min_cov=2, min_len=15, trim=5, min_weight=1)
+
+
+def test_config1_shape(gpu_ctx_factory):
+    """BASELINE configs[0]: single 1 kb backbone, 20x reads, default options."""
+    batch = synth.make_batch(1, 1000, 20, seed=1)
+    _, got = _check_batch(gpu_ctx_factory, batch, min_cov=6, min_len=500, trim=50)
+    assert len(got[0]) >= 1
+
+
+def test_midsize_synthetic(gpu_ctx_factory):
+    """64 targets x 2 kb x 24x and mixed lengths / partial spans (config-5 shape, scaled)."""
+    b1 = synth.make_batch(64, 2000, 24, seed=500)
+    _check_batch(gpu_ctx_factory, b1, min_cov=6, min_len=500, trim=50)
+    tl = np.random.default_rng(3).integers(600, 4000, 48)
+    b2 = synth.make_batch(48, 0, 16, seed=900, min_span=0.6, tlens=tl)
+    _check_batch(gpu_ctx_factory, b2, min_cov=6, min_len=500, trim=10)
+
+
+# ---- edge cases ---------------------------------------------------------------
+
+def test_empty_and_filtered(gpu_ctx_factory):
+    ctx = gpu_ctx_factory(min_cov=6, min_len=500, trim=50)
+    # empty batch
+    empty = capi.HostBatch(np.zeros(0, np.uint32), np.zeros(1, np.uint64), np.zeros(0, np.uint32),
+                           np.zeros(0, np.uint64), np.zeros(0, np.uint32), b"", b"")
+    assert ctx.consensus(empty) == []
+    # a target below min_cov, a target with no alignments, a normal one
+    rng = np.random.default_rng(5)
+    a1, bb1 = random_target(rng, 700, 3, full_span=True)
+    a3, bb3 = random_target(rng, 900, 9, full_span=True)
+    batch = batch_from_targets([(700, a1, bb1), (50, [], b"A" * 50), (900, a3, bb3)])
+    got = ctx.consensus(batch)
+    assert got[0] == [] and got[1] == []
+    assert got == oracle_batch(batch, 6, 500, 50)
+
+
+def test_all_alignments_below_min_len(gpu_ctx_factory):
+    """Every alignment is dropped by main.cpp:132 but the group still passes
+    main.cpp:118: the graph is the bare 'N' backbone."""
+    rng = np.random.default_rng(6)
+    alns, bb = random_target(rng, 30, 7, full_span=True)
+    batch = batch_from_targets([(30, alns, bb)])
+    for mw in (0, 1, 2):
+        _check_batch(gpu_ctx_factory, batch, min_cov=2, min_len=100, trim=0, min_weight=mw)
+
+
+def test_alignment_trimmed_to_nothing(gpu_ctx_factory):
+    """trimAln can leave empty strings (AlignmentTest.cpp:126-141); addAln then
+    only adds enter->exit (AlnGraphBoost.cpp:106)."""
+    rng = np.random.default_rng(8)
+    alns, bb = random_target(rng, 40, 6, full_span=True)
+    short = (5, b"ACGT", b"ACGT")
+    batch = batch_from_targets([(40, alns + [short, short], bb)])
+    _check_batch(gpu_ctx_factory, batch, min_cov=0, min_len=0, trim=3, min_weight=0)
+    _check_batch(gpu_ctx_factory, batch, min_cov=0, min_len=0, trim=30, min_weight=0)
+
+
+def test_nonconforming_is_rejected(gpu_ctx_factory):
+    ctx = gpu_ctx_factory(min_cov=0, min_len=0, trim=0, min_weight=0)
+    # start = 0 aliases the enter vertex (AlnGraphBoostTest.cpp:49-57 relies on UB)
+    with pytest.raises(capi.DagconError) as e:
+        ctx.consensus(batch_from_targets([(12, [(0, b"CCGCGG-G-A-T", b"C-GCGGA-T-G-")], b"N" * 12)]))
+    assert e.value.code == -4
+    # target bases run past tlen
+    with pytest.raises(capi.DagconError) as e:
+        ctx.consensus(batch_from_targets([(3, [(1, b"ACGTA", b"ACGTA")], b"NNN")]))
+    assert e.value.code == -4
+    # a byte outside printable ASCII
+    with pytest.raises(capi.DagconError) as e:
+        ctx.consensus(batch_from_targets([(5, [(1, b"AC\x01TA", b"ACGTA")], b"NNNNN")]))
+    assert e.value.code == -4
+    # the context is still usable afterwards
+    ok = ctx.consensus(batch_from_targets([(5, [(1, b"ACGTA", b"ACGTA")], b"NNNNN")]))
+    assert ok[0] == [(0, 5, b"ACGTA")]
+
+
+def test_deep_coverage_more_than_one_wave(gpu_ctx_factory):
+    """More than 64 alignments per target: adjacency rows span several waves."""
+    rng = np.random.default_rng(12)
+    alns, bb = random_target(rng, 80, 150, alphabet=b"ACGT", full_span=False)
+    alns2, bb2 = random_target(rng, 60, 70, alphabet=b"AC", full_span=True)
+    batch = batch_from_targets([(80, alns, bb), (60, alns2, bb2)])
+    _check_batch(gpu_ctx_factory, batch, min_cov=6, min_len=10, trim=2)
+
+
+def test_idempotent_reruns_same_context(gpu_ctx_factory):
+    """Same context, same resident batch, run twice: identical output (no state leaks
+    between runs, workspace reuse is clean)."""
+    batch = synth.make_batch(8, 1500, 20, seed=77)
+    ctx = gpu_ctx_factory(min_cov=6, min_len=500, trim=50)
+    ctx.upload(batch)
+    ctx.run(); a = ctx.fetch()
+    ctx.run(); b = ctx.fetch()
+    assert a == b == oracle_batch(batch, 6, 500, 50)
