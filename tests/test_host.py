@@ -1,0 +1,101 @@
+"""Host logic on CPU: synthetic generator, sharding, the FASTA gather over a
+2-rank gloo group, the .m5 reader."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_synth_is_deterministic_and_shard_independent():
+    from pbdagcon_amd import synth
+    a = synth.make_batch(6, 400, 8, seed=42)
+    b = synth.make_batch(6, 400, 8, seed=42)
+    assert np.array_equal(a.qstr, b.qstr) and np.array_equal(a.tstr, b.tstr)
+    # a target's data depends only on its global index, not on the shard it is generated in
+    c = synth.make_batch(3, 400, 8, seed=42, first_target=3)
+    for t in range(3):
+        assert c.target_alignments(t) == a.target_alignments(3 + t)
+    assert c.ids[0] == a.ids[3]
+
+
+def test_synth_shape():
+    from pbdagcon_amd import synth
+    b = synth.make_batch(2, 2000, 10, seed=5, with_backbone=True)
+    for t in range(2):
+        for s, q, tt in b.target_alignments(t):
+            assert len(q) == len(tt) and s == 1
+            tb = bytes(c for c in tt if c != 0x2D)
+            o = int(b.backbone_off[t])
+            assert tb == b.backbone[o:o + 2000].tobytes()       # target side spells the backbone
+            assert not any(x == 0x2D and y == 0x2D for x, y in zip(q, tt))
+    p = synth.make_batch(4, 1000, 6, seed=9, min_span=0.6)
+    for t in range(4):
+        for s, q, tt in p.target_alignments(t):
+            nt = sum(1 for c in tt if c != 0x2D)
+            assert nt >= 600 and s - 1 + nt <= 1000
+
+
+def test_shard_ranges_cover_and_balance():
+    from pbdagcon_amd.shard import shard_ranges
+    rng = np.random.default_rng(0)
+    w = rng.integers(1, 1000, 1000)
+    for world in (1, 2, 3, 8):
+        r = shard_ranges(w, world)
+        assert r[0][0] == 0 and r[-1][1] == 1000
+        assert all(r[i][1] == r[i + 1][0] for i in range(world - 1))
+        loads = [w[a:b].sum() for a, b in r]
+        assert max(loads) - min(loads) <= 2 * w.max()
+    assert shard_ranges([], 4) == [(0, 0)] * 4
+
+
+WORKER = r'''
+import os, sys
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import torch, torch.distributed as dist
+from pbdagcon_amd import synth
+from pbdagcon_amd.shard import shard_ranges, gather_fasta
+from util import oracle_batch
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+full = synth.make_batch(7, 300, 8, seed=3)
+w = [int(full.aln_len[int(full.aln_begin[t]):int(full.aln_begin[t+1])].sum()) for t in range(7)]
+lo, hi = shard_ranges(w, world)[rank]
+mine = full.select(range(lo, hi))
+# the compute leg of this CPU test is the checker; on the GPU box the same
+# plumbing carries the HIP results (bench.py)
+res = oracle_batch(mine, 4, 100, 10)
+def fasta(b, rs):
+    return b"".join(b">%s/%d_%d\n%s\n" % (b.ids[t].encode(), r0, r1, s) for t, segs in enumerate(rs) for r0, r1, s in segs)
+got = gather_fasta(fasta(mine, res), dist, torch)
+if rank == 0:
+    exp = fasta(full, oracle_batch(full, 4, 100, 10))
+    assert got == exp, "gathered FASTA differs from the single-rank result"
+    assert len(exp) > 0
+    print("GATHER_OK", len(got))
+else:
+    assert got is None
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_two_rank_gloo_gather(tmp_path):
+    """world_size 2 on CPU: contiguous shards + the gather reproduce the
+    single-rank FASTA byte for byte."""
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER.format(root=ROOT))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    out = subprocess.run(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+         "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
+        env=env, capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "GATHER_OK" in out.stdout
