@@ -166,7 +166,9 @@ int dagcon_normalize(dagcon_ctx *ctx, uint32_t n, const uint32_t *aln_start,
 
 /*
  * Debug / parity aid: adjacency of one target's graph as left by the last
- * dagcon_run (after mergeNodes), in list order.  Node arrays have *n_nodes
+ * dagcon_run (after mergeNodes), in list order.  Vertex ids are in backbone
+ * position order: the inserted vertices whose _bbMap is p (in read, column
+ * order), then backbone vertex p, for p = 0 .. tlen+1.  Node arrays have n_nodes
  * entries; out lists are CSR (out_begin[n_nodes+1], out_dst, out_count), in
  * lists likewise.  Buffers are owned by the context (valid until next call).
  */
@@ -176,6 +178,8 @@ typedef struct dagcon_graph_dump {
     const int32_t *weight;
     const int32_t *coverage;     /* meaningful for backbone vertices */
     const uint8_t *deleted;
+    const uint8_t *backbone;     /* 1 for enter / backbone / exit vertices */
+    const int32_t *bbpos;        /* backbone position (backbone vertices), _bbMap (inserted vertices) */
     const uint32_t *out_begin;
     const int32_t *out_dst;
     const int32_t *out_count;

@@ -69,7 +69,8 @@ class Timings(C.Structure):
 class GraphDump(C.Structure):
     _fields_ = [("n_nodes", C.c_uint32), ("base", C.POINTER(C.c_uint8)),
                 ("weight", C.POINTER(C.c_int32)), ("coverage", C.POINTER(C.c_int32)),
-                ("deleted", C.POINTER(C.c_uint8)), ("out_begin", C.POINTER(C.c_uint32)),
+                ("deleted", C.POINTER(C.c_uint8)), ("backbone", C.POINTER(C.c_uint8)),
+                ("bbpos", C.POINTER(C.c_int32)), ("out_begin", C.POINTER(C.c_uint32)),
                 ("out_dst", C.POINTER(C.c_int32)), ("out_count", C.POINTER(C.c_int32)),
                 ("in_begin", C.POINTER(C.c_uint32)), ("in_src", C.POINTER(C.c_int32))]
 
@@ -267,15 +268,17 @@ class Context:
         return res
 
     def debug_graph(self, target=0):
-        """Adjacency in list order, same shape as oracle.Graph.adjacency()."""
+        """Per vertex (device ids, backbone-position order):
+        dict(base, weight, coverage, deleted, backbone, bbpos, out=[(dst,count)], inn=[src])."""
         d = GraphDump()
         self._chk(self.L.dagcon_debug_graph(self.h, target, C.byref(d)))
         out = []
         for v in range(d.n_nodes):
             oe = [(d.out_dst[i], d.out_count[i]) for i in range(d.out_begin[v], d.out_begin[v + 1])]
             ie = [d.in_src[i] for i in range(d.in_begin[v], d.in_begin[v + 1])]
-            out.append((chr(d.base[v]), d.weight[v], d.coverage[v] if v < d.n_nodes else 0,
-                        bool(d.deleted[v]), oe, ie))
+            out.append(dict(base=chr(d.base[v]), weight=d.weight[v], coverage=d.coverage[v],
+                            deleted=bool(d.deleted[v]), backbone=bool(d.backbone[v]), bbpos=d.bbpos[v],
+                            out=oe, inn=ie))
         return out
 
 

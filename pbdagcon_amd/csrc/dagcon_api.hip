@@ -46,10 +46,10 @@ struct Ctx {
     // device buffers
     DevBuf d_q, d_t, d_aln_off, d_aln_len, d_aln_start, d_aln_tgt, d_tlen, d_aln_begin, d_tactive,
         d_bb, d_bb_off, d_mat_base, d_bbv_base;
-    DevBuf d_nmis, d_norm_off, d_n_lo, d_n_hi, d_n_start, d_n_ins, d_n_del, d_ins_base, d_norm;
-    DevBuf d_node_base, d_n_nodes, d_pool_base, d_pool_size, d_pool_top;
-    DevBuf d_matA, d_matD, d_cov, d_bvote;
-    DevBuf d_hot, d_lists, d_weight, d_bbpos, d_pending, d_best, d_queue, d_score, d_cns_tmp;
+    DevBuf d_nmis, d_norm_off, d_n_lo, d_n_hi, d_n_start, d_n_ins, d_n_del, d_norm;
+    DevBuf d_node_base, d_n_nodes, d_pool_base, d_pool_size, d_pool_top, d_t_nins;
+    DevBuf d_matA, d_matD, d_matC, d_cov, d_gcount, d_gbase, d_bid;
+    DevBuf d_nodes, d_best, d_queue, d_score, d_cns_tmp;
     DevBuf d_pool, d_stk;
     DevBuf d_cns, d_cns_off, d_cns_len, d_seg_first, d_n_seg, d_seg_r0, d_seg_r1, d_st;
 
@@ -66,8 +66,8 @@ struct Ctx {
     std::vector<char> r_blob;
 
     // debug dump storage
-    std::vector<uint8_t> g_base, g_deleted;
-    std::vector<int32_t> g_weight, g_cov, g_out_dst, g_out_cnt, g_in_src;
+    std::vector<uint8_t> g_base, g_deleted, g_backbone;
+    std::vector<int32_t> g_weight, g_cov, g_bbpos, g_out_dst, g_out_cnt, g_in_src;
     std::vector<uint32_t> g_out_begin, g_in_begin;
 };
 
@@ -123,11 +123,7 @@ void free_buf(DevBuf &b) {
 
 int ensure_arenas(Ctx *c) {
     ENSURE(c, c->d_norm, c->norm_cap * sizeof(uint16_t));
-    ENSURE(c, c->d_hot, c->node_cap * sizeof(DgHot));
-    ENSURE(c, c->d_lists, c->node_cap * sizeof(DgLists));
-    ENSURE(c, c->d_weight, c->node_cap * 4);
-    ENSURE(c, c->d_bbpos, c->node_cap * 4);
-    ENSURE(c, c->d_pending, c->node_cap * 4);
+    ENSURE(c, c->d_nodes, c->node_cap * sizeof(DgNode));
     ENSURE(c, c->d_best, c->node_cap * 4);
     ENSURE(c, c->d_queue, c->node_cap * 4);
     ENSURE(c, c->d_score, c->node_cap * 4);
@@ -162,16 +158,15 @@ void fill_params(Ctx *c, DgParams &p) {
     p.nmis = (uint32_t *)c->d_nmis.p; p.norm_off = (uint64_t *)c->d_norm_off.p;
     p.n_lo = (uint32_t *)c->d_n_lo.p; p.n_hi = (uint32_t *)c->d_n_hi.p;
     p.n_start = (uint32_t *)c->d_n_start.p; p.n_ins = (uint32_t *)c->d_n_ins.p;
-    p.n_del = (uint32_t *)c->d_n_del.p; p.ins_base = (uint32_t *)c->d_ins_base.p;
+    p.n_del = (uint32_t *)c->d_n_del.p;
     p.norm = (uint16_t *)c->d_norm.p; p.norm_cap = c->norm_cap;
     p.node_base = (uint64_t *)c->d_node_base.p; p.n_nodes = (uint32_t *)c->d_n_nodes.p;
     p.pool_base = (uint64_t *)c->d_pool_base.p; p.pool_size = (uint32_t *)c->d_pool_size.p;
-    p.pool_top = (uint32_t *)c->d_pool_top.p;
-    p.matA = (uint32_t *)c->d_matA.p; p.matD = (uint32_t *)c->d_matD.p;
-    p.cov = (int32_t *)c->d_cov.p; p.bvote = (uint32_t *)c->d_bvote.p;
-    p.hot = (DgHot *)c->d_hot.p; p.lists = (DgLists *)c->d_lists.p;
-    p.weight = (int32_t *)c->d_weight.p; p.bbpos = (int32_t *)c->d_bbpos.p;
-    p.pending = (int32_t *)c->d_pending.p; p.best = (int32_t *)c->d_best.p;
+    p.pool_top = (uint32_t *)c->d_pool_top.p; p.t_nins = (uint32_t *)c->d_t_nins.p;
+    p.matA = (uint32_t *)c->d_matA.p; p.matD = (uint32_t *)c->d_matD.p; p.matC = (uint32_t *)c->d_matC.p;
+    p.cov = (int32_t *)c->d_cov.p; p.gcount = (uint32_t *)c->d_gcount.p;
+    p.gbase = (uint32_t *)c->d_gbase.p; p.bid = (uint32_t *)c->d_bid.p;
+    p.nodes = (DgNode *)c->d_nodes.p; p.best = (int32_t *)c->d_best.p;
     p.queue = (int32_t *)c->d_queue.p; p.score = (float *)c->d_score.p;
     p.cns_tmp = (uint8_t *)c->d_cns_tmp.p; p.node_cap = c->node_cap;
     p.pool = (uint32_t *)c->d_pool.p; p.pool_cap = c->pool_cap;
@@ -193,6 +188,7 @@ int launch_all(Ctx *c) {
     HIPCHK(c, hipMemsetAsync(c->d_st.p, 0, sizeof(DgStatus), s));
     HIPCHK(c, hipMemsetAsync(c->d_cns_len.p, 0, (size_t)c->T * 4, s));
     HIPCHK(c, hipMemsetAsync(c->d_n_seg.p, 0, (size_t)c->T * 4, s));
+    if (c->mat_cells) HIPCHK(c, hipMemsetAsync(c->d_matC.p, 0, c->mat_cells * 4, s));
     HIPCHK(c, hipEventRecord(c->ev[0], s));
     if (c->A > 0) {
         hipLaunchKernelGGL(k_count, dim3(c->A), dim3(256), 0, s, p);
@@ -205,12 +201,15 @@ int launch_all(Ctx *c) {
     }
     hipLaunchKernelGGL(k_carve, dim3(1), dim3(1024), 0, s, p);
     if (c->T > 0) {
+        const uint32_t rows4 = (c->max_tlen + 2 + 3) / 4;
+        hipLaunchKernelGGL(k_groups, dim3(c->T, rows4), dim3(256), 0, s, p);
+        hipLaunchKernelGGL(k_gscan, dim3(c->T), dim3(1024), 0, s, p);
         hipLaunchKernelGGL(k_init_nodes, dim3(c->T, (c->max_tlen + 2 + 255) / 256), dim3(256), 0, s, p);
         if (c->A > 0) hipLaunchKernelGGL(k_emit, dim3((c->A + 63) / 64), dim3(64), 0, s, p);
         const size_t lds = (size_t)4 * 2 * (c->max_k + 2) * sizeof(int32_t);
         if (lds > 65536)
             HIPCHK(c, hipFuncSetAttribute((const void *)k_lists, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_lists, dim3(c->T, (c->max_tlen + 2 + 3) / 4), dim3(256), lds, s, p);
+        hipLaunchKernelGGL(k_lists, dim3(c->T, rows4), dim3(256), lds, s, p);
     }
     HIPCHK(c, hipEventRecord(c->ev[2], s));
     if (c->T > 0 && !(c->opts.flags & DAGCON_FLAG_STOP_AFTER_BUILD))
@@ -269,9 +268,9 @@ void dagcon_destroy(dagcon_ctx *ctx) {
     DevBuf *all[] = {&c->d_q, &c->d_t, &c->d_aln_off, &c->d_aln_len, &c->d_aln_start, &c->d_aln_tgt,
                      &c->d_tlen, &c->d_aln_begin, &c->d_tactive, &c->d_bb, &c->d_bb_off, &c->d_mat_base,
                      &c->d_bbv_base, &c->d_nmis, &c->d_norm_off, &c->d_n_lo, &c->d_n_hi, &c->d_n_start,
-                     &c->d_n_ins, &c->d_n_del, &c->d_ins_base, &c->d_norm, &c->d_node_base, &c->d_n_nodes,
-                     &c->d_pool_base, &c->d_pool_size, &c->d_pool_top, &c->d_matA, &c->d_matD, &c->d_cov,
-                     &c->d_bvote, &c->d_hot, &c->d_lists, &c->d_weight, &c->d_bbpos, &c->d_pending,
+                     &c->d_n_ins, &c->d_n_del, &c->d_norm, &c->d_node_base, &c->d_n_nodes,
+                     &c->d_pool_base, &c->d_pool_size, &c->d_pool_top, &c->d_t_nins, &c->d_matA, &c->d_matD,
+                     &c->d_matC, &c->d_cov, &c->d_gcount, &c->d_gbase, &c->d_bid, &c->d_nodes,
                      &c->d_best, &c->d_queue, &c->d_score, &c->d_cns_tmp, &c->d_pool, &c->d_stk, &c->d_cns,
                      &c->d_cns_off, &c->d_cns_len, &c->d_seg_first, &c->d_n_seg, &c->d_seg_r0, &c->d_seg_r1,
                      &c->d_st};
@@ -375,11 +374,14 @@ int dagcon_upload(dagcon_ctx *ctx, const dagcon_batch *b) {
     const size_t A4 = (size_t)c->A * 4, T4 = (size_t)T * 4;
     ENSURE(c, c->d_nmis, A4); ENSURE(c, c->d_norm_off, (size_t)c->A * 8);
     ENSURE(c, c->d_n_lo, A4); ENSURE(c, c->d_n_hi, A4); ENSURE(c, c->d_n_start, A4);
-    ENSURE(c, c->d_n_ins, A4); ENSURE(c, c->d_n_del, A4); ENSURE(c, c->d_ins_base, A4);
+    ENSURE(c, c->d_n_ins, A4); ENSURE(c, c->d_n_del, A4);
     ENSURE(c, c->d_node_base, (size_t)T * 8); ENSURE(c, c->d_n_nodes, T4);
     ENSURE(c, c->d_pool_base, (size_t)T * 8); ENSURE(c, c->d_pool_size, T4); ENSURE(c, c->d_pool_top, T4);
+    ENSURE(c, c->d_t_nins, T4);
     ENSURE(c, c->d_matA, c->mat_cells * 4); ENSURE(c, c->d_matD, c->mat_cells * 4);
-    ENSURE(c, c->d_cov, c->sum_bb * 4); ENSURE(c, c->d_bvote, c->sum_bb * 4);
+    ENSURE(c, c->d_matC, c->mat_cells * 4);
+    ENSURE(c, c->d_cov, c->sum_bb * 4); ENSURE(c, c->d_gcount, c->sum_bb * 4);
+    ENSURE(c, c->d_gbase, c->sum_bb * 4); ENSURE(c, c->d_bid, c->sum_bb * 4);
     ENSURE(c, c->d_cns_off, (size_t)T * 8); ENSURE(c, c->d_cns_len, T4);
     ENSURE(c, c->d_seg_first, (size_t)T * 8); ENSURE(c, c->d_n_seg, T4);
 
@@ -387,7 +389,7 @@ int dagcon_upload(dagcon_ctx *ctx, const dagcon_batch *b) {
     // small records the exact need on the device and is repeated once.
     c->norm_cap = std::max<uint64_t>(c->norm_cap, c->sum_len + c->sum_len / 32 + 8ull * c->A + 1024);
     c->node_cap = std::max<uint64_t>(c->node_cap, c->sum_bb + c->sum_len / 7 + 1024);
-    c->pool_cap = std::max<uint64_t>(c->pool_cap, 22ull * c->node_cap);
+    c->pool_cap = std::max<uint64_t>(c->pool_cap, 8ull * c->node_cap + 80ull * c->sum_bb + 1024ull * T);
     c->cns_cap = std::max<uint64_t>(c->cns_cap, c->sum_bb + c->sum_bb / 4 + 1024);
     c->seg_cap = std::max<uint64_t>(c->seg_cap, (uint64_t)T * 4 + 1024);
     if ((r = ensure_arenas(c))) return r;
@@ -628,37 +630,40 @@ int dagcon_debug_graph(dagcon_ctx *ctx, uint32_t target, dagcon_graph_dump *out)
     HIPCHK(c, hipMemcpy(&N, (uint32_t *)c->d_n_nodes.p + target, 4, hipMemcpyDeviceToHost));
     HIPCHK(c, hipMemcpy(&psz, (uint32_t *)c->d_pool_top.p + target, 4, hipMemcpyDeviceToHost));
     if (!c->h_tactive[target]) N = 0;
-    std::vector<DgHot> hot(N);
-    std::vector<DgLists> ls(N);
+    std::vector<DgNode> nd(N);
     std::vector<uint32_t> pool(psz);
+    std::vector<int32_t> cov(c->h_tlen[target] + 2, 0);
     c->g_weight.assign(N, 0); c->g_cov.assign(N, 0);
     if (N) {
-        HIPCHK(c, hipMemcpy(hot.data(), (DgHot *)c->d_hot.p + nb, (size_t)N * sizeof(DgHot), hipMemcpyDeviceToHost));
-        HIPCHK(c, hipMemcpy(ls.data(), (DgLists *)c->d_lists.p + nb, (size_t)N * sizeof(DgLists), hipMemcpyDeviceToHost));
-        HIPCHK(c, hipMemcpy(c->g_weight.data(), (int32_t *)c->d_weight.p + nb, (size_t)N * 4, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(nd.data(), (DgNode *)c->d_nodes.p + nb, (size_t)N * sizeof(DgNode), hipMemcpyDeviceToHost));
         const uint32_t nbb = c->h_tlen[target] + 2;
-        HIPCHK(c, hipMemcpy(c->g_cov.data(), (int32_t *)c->d_cov.p + c->h_bbv_base[target], (size_t)nbb * 4, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(cov.data(), (int32_t *)c->d_cov.p + c->h_bbv_base[target], (size_t)nbb * 4, hipMemcpyDeviceToHost));
         if (psz) HIPCHK(c, hipMemcpy(pool.data(), (uint32_t *)c->d_pool.p + pb, (size_t)psz * 4, hipMemcpyDeviceToHost));
     }
-    c->g_base.assign(N, 0); c->g_deleted.assign(N, 0);
+    c->g_base.assign(N, 0); c->g_deleted.assign(N, 0); c->g_backbone.assign(N, 0); c->g_bbpos.assign(N, 0);
     c->g_out_begin.assign(N + 1, 0); c->g_in_begin.assign(N + 1, 0);
     c->g_out_dst.clear(); c->g_out_cnt.clear(); c->g_in_src.clear();
+    uint32_t nbb_seen = 0;
     for (uint32_t v = 0; v < N; v++) {
-        c->g_base[v] = hot[v].base;
-        c->g_deleted[v] = (hot[v].flags & DG_NF_DELETED) ? 1 : 0;
+        c->g_base[v] = nd[v].base;
+        c->g_weight[v] = nd[v].weight;
+        c->g_deleted[v] = (nd[v].flags & DG_NF_DELETED) ? 1 : 0;
+        c->g_backbone[v] = (nd[v].flags & DG_NF_BACKBONE) ? 1 : 0;
+        if (c->g_backbone[v]) { c->g_bbpos[v] = (int32_t)nbb_seen; c->g_cov[v] = cov[nbb_seen]; nbb_seen++; }
+        else c->g_bbpos[v] = nd[v].bbpos;
         c->g_out_begin[v] = (uint32_t)c->g_out_dst.size();
         c->g_in_begin[v] = (uint32_t)c->g_in_src.size();
-        for (uint32_t i = 0; i < hot[v].out_len; i++) {
-            c->g_out_dst.push_back((int32_t)pool[ls[v].out_off + 2 * i]);
-            c->g_out_cnt.push_back((int32_t)pool[ls[v].out_off + 2 * i + 1]);
+        for (uint32_t i = 0; i < nd[v].out_len; i++) {
+            c->g_out_dst.push_back((int32_t)pool[nd[v].out_off + 2 * i]);
+            c->g_out_cnt.push_back((int32_t)pool[nd[v].out_off + 2 * i + 1]);
         }
-        for (uint32_t i = 0; i < hot[v].in_len; i++) c->g_in_src.push_back((int32_t)pool[ls[v].in_off + i]);
+        for (uint32_t i = 0; i < nd[v].in_len; i++) c->g_in_src.push_back((int32_t)pool[nd[v].in_off + i]);
     }
     c->g_out_begin[N] = (uint32_t)c->g_out_dst.size();
     c->g_in_begin[N] = (uint32_t)c->g_in_src.size();
     out->n_nodes = N;
     out->base = c->g_base.data(); out->weight = c->g_weight.data(); out->coverage = c->g_cov.data();
-    out->deleted = c->g_deleted.data();
+    out->deleted = c->g_deleted.data(); out->backbone = c->g_backbone.data(); out->bbpos = c->g_bbpos.data();
     out->out_begin = c->g_out_begin.data(); out->out_dst = c->g_out_dst.data(); out->out_count = c->g_out_cnt.data();
     out->in_begin = c->g_in_begin.data(); out->in_src = c->g_in_src.data();
     return DAGCON_OK;

@@ -2,14 +2,17 @@
 //
 // One batch = T independent targets.  Everything lives in a handful of HBM
 // arenas owned by the context; per-target and per-alignment arrays hold
-// offsets into them.  Vertex ids are target-local int32:
-//     0            enter '^'          (AlnGraphBoost.cpp:26-28)
-//     1 .. blen    backbone
-//     blen+1       exit '$'
-//     blen+2 ..    inserted vertices, numbered per alignment in column order
-// Vertex ids are only names: what the reference's results depend on is the
-// ORDER of each vertex's out- and in-list, which is
-// kept exactly.
+// offsets into them.
+//
+// Vertex ids are target-local int32, numbered in BACKBONE-POSITION ORDER:
+//   for p = 0 .. blen+1:   [inserted vertices whose _bbMap is p, in (read, column) order]
+//                          [backbone vertex p]            (p = 0 enter '^', p = blen+1 exit '$')
+// so id(backbone p) = bid[p] = gbase[p] + gcount[p], enter = 0, exit = N-1, and every edge of
+// the freshly built graph runs from a lower id to a higher id.  Ids are only names: what the
+// reference's results depend on is the ORDER of each vertex's out- and in-list (SURVEY
+// Appendix A.1/A.2), which is kept exactly.  Position order makes the FIFO sweep of mergeNodes
+// and the reverse sweep of bestPath walk memory monotonically (cache lines are reused, not
+// re-fetched), which is what a latency-bound pointer chase needs.
 #pragma once
 #include <stdint.h>
 
@@ -19,16 +22,17 @@
 #define DG_F_RAW      1u
 #define DG_F_A1_ONLY  8u   // dagcon_normalize: no graph follows, skip the backbone conformity check
 
-// status bits (Status::err_flags)
+// status bits (DgStatus::err_flags)
 #define DG_E_BADCHAR     0x001u  // byte outside printable ASCII in an alignment string
 #define DG_E_NONCONF     0x002u  // alignment leaves the backbone (start<1 or runs past tlen)
-#define DG_E_NORM_OVF    0x004u  // normalised-column arena too small (rerun with norm_need)
+#define DG_E_NORM_OVF    0x004u  // normalised-column arena too small (rerun with norm_top)
 #define DG_E_NODE_OVF    0x008u  // vertex arena too small (rerun with node_need)
 #define DG_E_POOL_OVF    0x010u  // adjacency pool arena too small (rerun with pool_need)
 #define DG_E_POOL_TGT    0x020u  // one target outgrew its pool share (rerun with larger growth factor)
 #define DG_E_STACK       0x040u  // mergeInNodes recursion scratch exhausted
 #define DG_E_INTERNAL    0x080u  // invariant violated (empty list dereference, list > 65535)
 #define DG_E_OUT_OVF     0x100u  // output arena too small
+#define DG_E_TOO_BIG     0x200u  // a target has more than 2^25-2 vertices
 
 struct DgStatus {
     uint32_t err_flags;
@@ -43,23 +47,29 @@ struct DgStatus {
     unsigned long long n_columns;  // normalised, trimmed columns
 };
 
-// Per-vertex record gathered when a vertex is looked at as somebody's neighbour.
-struct DgHot {
+// One 32-byte record per vertex.  The first 16 bytes are what a neighbour needs to know
+// about it (one dwordx4 gather); the second 16 bytes say where its own lists live.
+// out entry i: pool[out_off + 2i] = dst, pool[out_off + 2i + 1] = count
+// in  entry i: pool[in_off + i]   = src          (edge counts live on the out side only)
+struct __attribute__((aligned(16))) DgNode {
     uint16_t out_len, in_len;
     uint8_t base, flags;
     uint16_t pad;
+    int32_t weight;
+    int32_t pending;               // in-edges whose source is not processed yet (merge);
+                                   // out-edges whose target is not scored yet (bestPath)
+    uint32_t out_off, in_off;
+    uint16_t out_cap, in_cap;
+    int32_t bbpos;                 // _bbMap: absent key (enter, exit) reads as 0
 };
 #define DG_NF_BACKBONE 1u
 #define DG_NF_DELETED  2u
 
-// Where a vertex's own adjacency lists live in the target's pool.
-// out entry i: pool[out_off + 2i] = dst, pool[out_off + 2i + 1] = count
-// in  entry i: pool[in_off + i]   = src          (edge counts live on the out side only)
-struct DgLists {
-    uint32_t out_off, in_off;
-    uint16_t out_cap, in_cap;
-    uint32_t pad;
-};
+// arrival cell: (target base << 25) | (source id + 1); deletion: id field all ones
+#define DG_CELL_ID(c)   ((c) & 0x1FFFFFFu)
+#define DG_CELL_DEL     0x1FFFFFFu
+#define DG_CELL_BASE(c) ((uint8_t)((c) >> 25))
+#define DG_MAX_NODES    0x1FFFFFDu
 
 struct DgParams {
     // ---- inputs (resident in HBM after dagcon_upload) ----
@@ -71,8 +81,8 @@ struct DgParams {
     const uint8_t *tactive;        // [T] 1 = build a graph (main.cpp:66-72,118)
     const uint8_t *bb;             // optional backbone blob
     const uint64_t *bb_off;
-    const uint64_t *mat_base;      // [T] offset into matA/matD: (tlen+2) * K cells
-    const uint64_t *bbv_base;      // [T] offset into cov/bvote: tlen+2 cells
+    const uint64_t *mat_base;      // [T] offset into matA/matD/matC: (tlen+2) * K cells
+    const uint64_t *bbv_base;      // [T] offset into the per-position arrays: tlen+2 cells
     uint32_t T, A;
     uint32_t trim, min_len;
     int32_t min_weight;
@@ -81,7 +91,7 @@ struct DgParams {
     // ---- per alignment work arrays ----
     uint32_t *nmis;
     uint64_t *norm_off;
-    uint32_t *n_lo, *n_hi, *n_start, *n_ins, *n_del, *ins_base;
+    uint32_t *n_lo, *n_hi, *n_start, *n_ins, *n_del;
     uint16_t *norm;                // column arena: low byte q, high byte t
     uint64_t norm_cap;
     // ---- per target work arrays ----
@@ -89,13 +99,18 @@ struct DgParams {
     uint32_t *n_nodes;
     uint64_t *pool_base;
     uint32_t *pool_size, *pool_top;
-    // ---- arenas ----
-    uint32_t *matA, *matD;         // arrival / departure matrices [vertex][read]
-    int32_t *cov;                  // backbone coverage
-    uint32_t *bvote;               // (read+1)<<8 | base : last writer wins (AlnGraphBoost.cpp:79,90)
-    DgHot *hot;
-    DgLists *lists;
-    int32_t *weight, *bbpos, *pending, *best, *queue;
+    uint32_t *t_nins;              // inserted vertices of the target
+    // ---- per backbone position (bbv_base indexed) ----
+    uint32_t *gcount;              // inserted vertices whose _bbMap is p
+    uint32_t *gbase;               // id of the first vertex of group p
+    uint32_t *bid;                 // id of backbone vertex p
+    int32_t *cov;                  // coverage (AlnGraphBoost.cpp:76,87)
+    // ---- matrices [position][read] ----
+    uint32_t *matA, *matD;         // arrival / departure
+    uint32_t *matC;                // insertion run length, then exclusive prefix over reads
+    // ---- vertex arena ----
+    DgNode *nodes;
+    int32_t *best, *queue;
     float *score;
     uint8_t *cns_tmp;
     uint64_t node_cap;
@@ -115,3 +130,7 @@ struct DgParams {
     uint64_t seg_cap;
     DgStatus *st;
 };
+
+// slots a backbone vertex gets for each of its two lists before it has to move to the
+// growth region (K = alignments of the target)
+__host__ __device__ inline uint32_t dg_capb(uint32_t k) { return k + 2u < 12u ? k + 2u : 12u; }

@@ -21,23 +21,18 @@ __global__ __launch_bounds__(64) void k_bestpath(DgParams p) {
     if (dg_failed(p) || !p.tactive[t]) return;
     const int lane = threadIdx.x;
     const uint64_t nb = p.node_base[t];
-    DgHot *hot = p.hot + nb;
-    const DgLists *ls = p.lists + nb;
-    const int32_t *weight = p.weight + nb;
-    const int32_t *bbpos = p.bbpos + nb;
-    int32_t *pend = p.pending + nb;
+    DgNode *nd = p.nodes + nb;
     int32_t *best = p.best + nb;
     int32_t *queue = p.queue + nb;
     float *score = p.score + nb;
     const int32_t *cov = p.cov + p.bbv_base[t];
     const uint32_t *pool = p.pool + p.pool_base[t];
     const uint32_t N = p.n_nodes[t];
-    const uint32_t blen = p.tlen[t];
-    const int exitv = (int)blen + 1;
+    const int exitv = (int)N - 1;
     __shared__ uint32_t s_qt;
 
     for (uint32_t v = lane; v < N; v += 64) {
-        pend[v] = hot[v].out_len;     // out-edges not yet visited (:423-439)
+        nd[v].pending = nd[v].out_len;   // out-edges not yet visited (:423-439)
         best[v] = -1;
         score[v] = 0.0f;              // std::map<VtxDesc,float>: absent key reads as 0
     }
@@ -49,20 +44,20 @@ __global__ __launch_bounds__(64) void k_bestpath(DgParams p) {
         int n = -1;
         if ((uint32_t)lane < m) {
             n = queue[qh + lane];
-            const uint32_t off = ls[n].out_off;
-            const int len = hot[n].out_len;
+            const uint32_t off = nd[n].out_off;
+            const int len = nd[n].out_len;
             float bs = -FLT_MAX;
             int bd = -1;
             for (int i = 0; i < len; i++) {
                 const int d = (int)pool[off + 2 * i];
                 const int cnt = (int)pool[off + 2 * i + 1];
-                const DgHot h = hot[d];
+                const DgNode h = nd[d];
                 const float s = score[d];
                 float ns;
-                if ((h.flags & DG_NF_BACKBONE) && weight[d] == 1) {
+                if ((h.flags & DG_NF_BACKBONE) && h.weight == 1) {
                     ns = s - 10.0f;
                 } else {
-                    const int c = cov[bbpos[d]];
+                    const int c = cov[h.bbpos];
                     ns = (float)cnt - (float)c * 0.5f + s;
                 }
                 if (ns > bs) { bs = ns; bd = d; }
@@ -71,11 +66,11 @@ __global__ __launch_bounds__(64) void k_bestpath(DgParams p) {
         }
         __syncthreads();              // scores of this wavefront land before anyone is released
         if (n >= 0) {
-            const uint32_t off = ls[n].in_off;
-            const int len = hot[n].in_len;
+            const uint32_t off = nd[n].in_off;
+            const int len = nd[n].in_len;
             for (int i = 0; i < len; i++) {
                 const int s = (int)pool[off + i];
-                if (atomicSub(&pend[s], 1) == 1) {
+                if (atomicSub(&nd[s].pending, 1) == 1) {
                     const uint32_t pos = atomicAdd(&s_qt, 1u);
                     if (pos < N) queue[pos] = s;
                 }
@@ -93,7 +88,7 @@ __global__ __launch_bounds__(64) void k_bestpath(DgParams p) {
     uint8_t *tmp = p.cns_tmp + nb;
     int32_t *segs = p.stk + (uint64_t)t * p.stk_words;      // (range0, range1) pairs
     if (lane == 0) {
-        const uint8_t eb = hot[0].base, xb = hot[exitv].base;
+        const uint8_t eb = nd[0].base, xb = nd[exitv].base;
         const int minw = p.min_weight;
         const uint32_t minlen = p.min_len;
         const uint32_t seg_cap = p.stk_words / 2;
@@ -103,11 +98,11 @@ __global__ __launch_bounds__(64) void k_bestpath(DgParams p) {
         uint32_t nseg = 0, steps = 0;
         bool ovf = false;
         for (;;) {
-            const DgHot h = hot[v];
+            const DgNode h = nd[v];
             const int nxt = best[v];
             if (!(h.base == eb || h.base == xb)) {
                 tmp[idx] = h.base;
-                const int w = weight[v];
+                const int w = h.weight;
                 if (!met && w >= minw) { offs = idx; met = true; }
                 else if (met && w < minw) {
                     met = false;

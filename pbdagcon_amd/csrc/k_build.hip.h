@@ -1,12 +1,17 @@
 // k_build.hip.h -- stage (a): alignment strings -> alignment DAG in HBM.
 //
 //   k_count      a1  mismatch count per alignment (sizes the column buffer), byte validation
-//   k_normalize  a1  normalizeGaps (Alignment.cpp:131-217) + trimAln (:219-242), one lane per alignment
+//   k_normalize  a1  normalizeGaps (Alignment.cpp:131-217) + trimAln (:219-242), one lane per
+//                    alignment; also records the insertion run length per (position, read)
 //   k_carve      a2  exact vertex / pool needs per target, exclusive scans -> arena offsets
+//   k_groups     a2  per backbone position: exclusive scan of insertion run lengths over reads
+//   k_gscan      a2  per target: exclusive scan over positions -> position-ordered vertex ids
 //   k_init_nodes a2  backbone vertices (AlnGraphBoost.cpp:16-62)
-//   k_emit       a2  addAln (AlnGraphBoost.cpp:64-107): one lane per alignment walks its columns
-//   k_lists      a2  addEdge dedupe (AlnGraphBoost.cpp:109-127): one wave per backbone vertex turns
-//                    its arrival / departure row into ordered adjacency lists (ballot / popcount)
+//   k_emit       a2  addAln (AlnGraphBoost.cpp:64-107): one lane per alignment walks its columns;
+//                    plain stores only (arrival / departure cells, inserted vertex records)
+//   k_lists      a2  addEdge dedupe (AlnGraphBoost.cpp:109-127) + coverage / weight / base:
+//                    one wave per backbone position turns its arrival / departure row into
+//                    ordered adjacency lists (ballot / popcount peeling)
 #pragma once
 #include <hip/hip_runtime.h>
 #include "dagcon_dev.h"
@@ -47,7 +52,7 @@ __global__ __launch_bounds__(256) void k_count(DgParams p) {
     if (threadIdx.x == 0) {
         mis = s_mis[0] + s_mis[1] + s_mis[2] + s_mis[3];
         bad = s_bad[0] | s_bad[1] | s_bad[2] | s_bad[3];
-        if (p.flags & 1u) mis = 0;   // raw mode: columns are taken as they are
+        if (p.flags & DG_F_RAW) mis = 0;   // raw mode: columns are taken as they are
         if (bad) { dg_fail(p, DG_E_BADCHAR); p.st->bad_aln = a; }
         p.nmis[a] = mis;
         unsigned long long cap = ((unsigned long long)len + mis + 7ull) & ~7ull;
@@ -74,7 +79,7 @@ __global__ __launch_bounds__(64) void k_normalize(DgParams p) {
     const uint32_t len = p.aln_len[a];
     const uint8_t *q = p.q + off, *t = p.t + off;
     uint16_t *buf = p.norm + p.norm_off[a];
-    const bool raw = (p.flags & 1u) != 0;
+    const bool raw = (p.flags & DG_F_RAW) != 0;
 
     // Alignment.cpp:142-159: dots to dashes, mismatches to a deletion + an insertion
     uint32_t n = 0;
@@ -159,29 +164,50 @@ __global__ __launch_bounds__(64) void k_normalize(DgParams p) {
     }
     p.n_lo[a] = lo; p.n_hi[a] = hi; p.n_start[a] = start;
     p.n_ins[a] = n_ins; p.n_del[a] = n_del;
-    const uint32_t tlen = p.tlen[p.aln_tgt[a]];
-    if (!(p.flags & DG_F_A1_ONLY) && hi > lo && (start < 1 || (uint64_t)start - 1 + adv > (uint64_t)tlen)) {
+    atomicAdd(&p.st->n_columns, (unsigned long long)(hi - lo));
+    if (p.flags & DG_F_A1_ONLY) return;
+    const uint32_t t_idx = p.aln_tgt[a];
+    const uint32_t tlen = p.tlen[t_idx];
+    if (hi > lo && (start < 1 || (uint64_t)start - 1 + adv > (uint64_t)tlen)) {
         dg_fail(p, DG_E_NONCONF);
         p.st->bad_aln = a;
+        return;
     }
-    atomicAdd(&p.st->n_columns, (unsigned long long)(hi - lo));
+    // insertion run length per (position, read): numbers the inserted vertices
+    if (n_ins && p.tactive[t_idx]) {
+        const uint64_t ab = p.aln_begin[t_idx];
+        const uint32_t r = (uint32_t)(a - ab);
+        const uint32_t K = (uint32_t)(p.aln_begin[t_idx + 1] - ab);
+        uint32_t *Cm = p.matC + p.mat_base[t_idx];
+        uint32_t bbpos = start, run = 0;
+        for (uint32_t i = lo; i < hi; i++) {
+            uint16_t c = buf[i];
+            uint8_t qb = DG_Q(c), tb = DG_T(c);
+            if (qb == tb || qb == DG_GAP) {
+                if (run) { Cm[(uint64_t)bbpos * K + r] = run; run = 0; }
+                bbpos++;
+            } else if (tb == DG_GAP) run++;
+        }
+        if (run) Cm[(uint64_t)bbpos * K + r] = run;
+    }
 }
 
 // ---------------------------------------------------------------------------
 // k_carve: a single 1024-thread block.  Exact sizes per target, then
 // exclusive scans over targets for the arena offsets.
+// Pool of a target: [inserted vertices: 3 words each, id order]
+//                   [backbone positions: 3*capb words each] [growth region]
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t dg_pool_words(uint32_t tlen, uint32_t n_ins, uint32_t n_del,
-                                                  uint32_t k, uint32_t growth_pct, uint32_t *ins_words) {
-    // backbone lists: every list has the constructor edge plus at most one
-    // entry per insertion run / deletion run / read end that touches it;
-    // 2 spare slots per list.  out entries take 2 words, in entries 1.
-    uint64_t bb_entries = (uint64_t)(tlen + 2) * 3ull + n_ins + n_del + 2ull * k;
-    uint64_t bb_words = 3ull * bb_entries;
-    uint64_t iw = 3ull * n_ins;
-    uint64_t growth = ((bb_words + iw) * growth_pct) / 100ull + 256ull;
-    *ins_words = (uint32_t)iw;
-    uint64_t tot = bb_words + iw + growth;
+                                                  uint32_t k, uint32_t growth_pct, uint32_t *fixed_words) {
+    const uint64_t capb = dg_capb(k);
+    const uint64_t fixed = 3ull * n_ins + (uint64_t)(tlen + 2) * 3ull * capb;
+    // rows that outgrow capb move to the growth region: every entry beyond the constructor
+    // edge comes from an insertion run, a deletion run or a read end
+    const uint64_t spill = 3ull * ((uint64_t)n_ins + n_del + 2ull * k) + 64ull;
+    const uint64_t growth = (fixed * growth_pct) / 100ull + spill + 256ull;
+    *fixed_words = (uint32_t)fixed;
+    const uint64_t tot = fixed + growth;
     return tot > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)tot;
 }
 
@@ -195,19 +221,15 @@ __global__ __launch_bounds__(1024) void k_carve(DgParams p) {
     for (uint32_t t0 = 0; t0 < p.T; t0 += 1024) {
         const uint32_t t = t0 + tid;
         unsigned long long nodes = 0, poolw = 0;
-        uint32_t ins_words = 0;
+        uint32_t fixed_words = 0, ins = 0;
         if (t < p.T && p.tactive[t]) {
-            uint32_t ins = 0, del = 0;
+            uint32_t del = 0;
             const uint64_t b = p.aln_begin[t], e = p.aln_begin[t + 1];
-            for (uint64_t a = b; a < e; a++) {
-                p.ins_base[a] = ins;
-                ins += p.n_ins[a];
-                del += p.n_del[a];
-            }
+            for (uint64_t a = b; a < e; a++) { ins += p.n_ins[a]; del += p.n_del[a]; }
             nodes = (unsigned long long)p.tlen[t] + 2ull + ins;
-            poolw = dg_pool_words(p.tlen[t], ins, del, (uint32_t)(e - b), p.growth_pct, &ins_words);
+            if (nodes > DG_MAX_NODES) { dg_fail(p, DG_E_TOO_BIG); p.st->bad_target = t; }
+            poolw = dg_pool_words(p.tlen[t], ins, del, (uint32_t)(e - b), p.growth_pct, &fixed_words);
         }
-        // block exclusive scan of nodes
         s_scan[tid] = nodes;
         __syncthreads();
         for (uint32_t o = 1; o < 1024; o <<= 1) {
@@ -235,7 +257,8 @@ __global__ __launch_bounds__(1024) void k_carve(DgParams p) {
             p.n_nodes[t] = (uint32_t)nodes;
             p.pool_base[t] = pool_excl;
             p.pool_size[t] = (uint32_t)poolw;
-            p.pool_top[t] = ins_words;      // inserted vertices own the first 3*n_ins words
+            p.pool_top[t] = fixed_words;
+            p.t_nins[t] = ins;
         }
         if (tid == 0) { s_carry_nodes += node_tot; s_carry_pool += pool_tot; }
         __syncthreads();
@@ -249,31 +272,95 @@ __global__ __launch_bounds__(1024) void k_carve(DgParams p) {
 }
 
 // ---------------------------------------------------------------------------
-// k_init_nodes: grid (T, chunks of 256 backbone vertices).
+// k_groups: one wave per backbone position.  matC row -> exclusive prefix over
+// reads (in place); gcount[p] = inserted vertices whose _bbMap is p.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_groups(DgParams p) {
+    const uint32_t t = blockIdx.x;
+    if (dg_failed(p) || !p.tactive[t]) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t blen = p.tlen[t];
+    const uint32_t pos = blockIdx.y * 4 + wave;
+    if (pos >= blen + 2) return;
+    const uint32_t K = (uint32_t)(p.aln_begin[t + 1] - p.aln_begin[t]);
+    uint32_t *row = p.matC + p.mat_base[t] + (uint64_t)pos * K;
+    uint32_t carry = 0;
+    for (uint32_t r0 = 0; r0 < K; r0 += DG_WAVE) {
+        const uint32_t r = r0 + lane;
+        const uint32_t v = r < K ? row[r] : 0u;
+        uint32_t incl = v;
+        for (int o = 1; o < DG_WAVE; o <<= 1) {
+            const uint32_t up = __shfl_up(incl, o);
+            if (lane >= o) incl += up;
+        }
+        if (r < K) row[r] = carry + incl - v;
+        carry += __shfl(incl, DG_WAVE - 1);
+    }
+    if (lane == 0) p.gcount[p.bbv_base[t] + pos] = carry;
+}
+
+// ---------------------------------------------------------------------------
+// k_gscan: one 1024-thread block per target: gbase[p] = sum_{p'<p} (gcount[p'] + 1).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_gscan(DgParams p) {
+    __shared__ uint32_t s_scan[1024];
+    __shared__ uint32_t s_carry;
+    const uint32_t t = blockIdx.x;
+    if (dg_failed(p) || !p.tactive[t]) return;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t np = p.tlen[t] + 2;
+    const uint64_t bv = p.bbv_base[t];
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (uint32_t p0 = 0; p0 < np; p0 += 1024) {
+        const uint32_t pos = p0 + tid;
+        const uint32_t gc = pos < np ? p.gcount[bv + pos] : 0u;
+        const uint32_t v = pos < np ? gc + 1u : 0u;
+        s_scan[tid] = v;
+        __syncthreads();
+        for (uint32_t o = 1; o < 1024; o <<= 1) {
+            uint32_t x = tid >= o ? s_scan[tid - o] : 0;
+            __syncthreads();
+            s_scan[tid] += x;
+            __syncthreads();
+        }
+        const uint32_t excl = s_scan[tid] - v + s_carry;
+        const uint32_t tot = s_scan[1023];
+        __syncthreads();
+        if (pos < np) { p.gbase[bv + pos] = excl; p.bid[bv + pos] = excl + gc; }
+        if (tid == 0) s_carry += tot;
+        __syncthreads();
+    }
+    if (tid == 0 && s_carry != p.n_nodes[t]) { dg_fail(p, DG_E_INTERNAL); p.st->bad_target = t; }
+}
+
+// ---------------------------------------------------------------------------
+// k_init_nodes: grid (T, chunks of 256 backbone positions).
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_init_nodes(DgParams p) {
     const uint32_t t = blockIdx.x;
     if (dg_failed(p) || !p.tactive[t]) return;
     const uint32_t blen = p.tlen[t];
-    const uint32_t v = blockIdx.y * 256 + threadIdx.x;
-    if (v >= blen + 2) return;
-    const uint64_t nb = p.node_base[t];
-    DgHot h;
-    h.out_len = 0; h.in_len = 0; h.flags = DG_NF_BACKBONE; h.pad = 0;
-    if (v == 0) h.base = '^';
-    else if (v == blen + 1) h.base = '$';
-    else h.base = p.bb ? p.bb[p.bb_off[t] + (v - 1)] : (uint8_t)'N';
-    p.hot[nb + v] = h;
-    const bool inner = (v >= 1 && v <= blen);
-    p.weight[nb + v] = inner ? 1 : 0;
-    p.bbpos[nb + v] = inner ? (int32_t)v : 0;   // _bbMap: absent key (enter, exit) reads as 0
-    const uint64_t bv = p.bbv_base[t] + v;
+    const uint32_t pos = blockIdx.y * 256 + threadIdx.x;
+    if (pos >= blen + 2) return;
+    const uint64_t bv = p.bbv_base[t] + pos;
+    const uint32_t v = p.bid[bv];
+    DgNode nd;
+    nd.out_len = 0; nd.in_len = 0; nd.flags = DG_NF_BACKBONE; nd.pad = 0;
+    if (pos == 0) nd.base = '^';
+    else if (pos == blen + 1) nd.base = '$';
+    else nd.base = p.bb ? p.bb[p.bb_off[t] + (pos - 1)] : (uint8_t)'N';
+    const bool inner = (pos >= 1 && pos <= blen);
+    nd.weight = inner ? 1 : 0;
+    nd.pending = 0;
+    nd.out_off = 0; nd.in_off = 0; nd.out_cap = 0; nd.in_cap = 0;
+    nd.bbpos = inner ? (int32_t)pos : 0;    // _bbMap: absent key (enter, exit) reads as 0
+    p.nodes[p.node_base[t] + v] = nd;
     p.cov[bv] = 0;
-    p.bvote[bv] = 0;
 }
 
 // ---------------------------------------------------------------------------
-// k_emit: addAln, one lane per alignment.
+// k_emit: addAln, one lane per alignment.  Plain stores only.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_emit(DgParams p) {
     const uint32_t a = blockIdx.x * 64 + threadIdx.x;
@@ -285,73 +372,68 @@ __global__ __launch_bounds__(64) void k_emit(DgParams p) {
     const uint32_t r = (uint32_t)(a - ab);
     const uint32_t K = (uint32_t)(p.aln_begin[t + 1] - ab);
     const uint32_t blen = p.tlen[t];
-    const uint32_t exitv = blen + 1;
+    const uint32_t exitpos = blen + 1;
     const uint64_t nb = p.node_base[t];
     const uint64_t bv = p.bbv_base[t];
+    const uint32_t *bid = p.bid + bv, *gbase = p.gbase + bv;
     uint32_t *Am = p.matA + p.mat_base[t];
     uint32_t *Dm = p.matD + p.mat_base[t];
+    const uint32_t *Cm = p.matC + p.mat_base[t];
     uint32_t *pool = p.pool + p.pool_base[t];
-    const uint32_t n_ins_t = p.pool_top[t] / 3u;   // carve left 3*n_ins here; k_lists bumps it later
     const uint16_t *buf = p.norm + p.norm_off[a];
     const uint32_t lo = p.n_lo[a], hi = p.n_hi[a];
     uint32_t bbpos = p.n_start[a];
-    uint32_t prev = 0;
-    uint32_t ins_idx = p.ins_base[a];     // index among the target's inserted vertices
+    uint32_t prev = 0;            // vertex id of the previous vertex on the read's path
+    uint32_t prev_pos = 0;        // its backbone position (_bbMap for an inserted vertex)
+    bool prev_bb = true;
+    uint32_t ins_id = 0, ins_pos = 0xFFFFFFFFu;   // next id inside the current insertion run
 
-#define DG_DEPART(PREV, NXT)                                              \
-    do {                                                                  \
-        if ((PREV) < blen + 2) Dm[(uint64_t)(PREV) * K + r] = (NXT) + 1u; \
-        else {                                                            \
-            uint32_t _i = (PREV) - (blen + 2);                            \
-            pool[2u * _i] = (NXT);                                        \
-            pool[2u * _i + 1u] = 1u;                                      \
-        }                                                                 \
+    // departure of `prev` to `nxt`: a matrix cell for backbone vertices, the single out
+    // slot for an inserted vertex (its rank among inserted vertices is id - position)
+#define DG_DEPART(NXT)                                                       \
+    do {                                                                     \
+        if (prev_bb) Dm[(uint64_t)prev_pos * K + r] = (NXT) + 1u;            \
+        else {                                                               \
+            const uint32_t _rk = prev - prev_pos;                            \
+            pool[3u * _rk] = (NXT);                                          \
+            pool[3u * _rk + 1u] = 1u;                                        \
+        }                                                                    \
     } while (0)
 
     for (uint32_t i = lo; i < hi; i++) {
         const uint16_t c = buf[i];
         const uint8_t qb = DG_Q(c), tb = DG_T(c);
         if (qb == tb) {                                   // match  (AlnGraphBoost.cpp:75-85)
-            atomicAdd(&p.cov[bv + bbpos], 1);
-            atomicMax(&p.bvote[bv + bbpos], ((r + 1u) << 8) | tb);
-            atomicAdd(&p.weight[nb + bbpos], 1);
-            Am[(uint64_t)bbpos * K + r] = prev + 1u;
-            DG_DEPART(prev, bbpos);
-            prev = bbpos;
+            const uint32_t cur = bid[bbpos];
+            Am[(uint64_t)bbpos * K + r] = ((uint32_t)tb << 25) | (prev + 1u);
+            DG_DEPART(cur);
+            prev = cur; prev_pos = bbpos; prev_bb = true;
             bbpos++;
         } else if (qb == DG_GAP) {                        // deletion (:87-93)
-            atomicAdd(&p.cov[bv + bbpos], 1);
-            atomicMax(&p.bvote[bv + bbpos], ((r + 1u) << 8) | tb);
+            Am[(uint64_t)bbpos * K + r] = ((uint32_t)tb << 25) | DG_CELL_DEL;
             bbpos++;
         } else if (tb == DG_GAP) {                        // insertion (:95-104)
-            const uint32_t id = blen + 2 + ins_idx;
-            DgHot h;
-            h.out_len = 1; h.in_len = 1; h.base = qb; h.flags = 0; h.pad = 0;
-            p.hot[nb + id] = h;
-            DgLists l;
-            l.out_off = 2u * ins_idx; l.in_off = 2u * n_ins_t + ins_idx;
-            l.out_cap = 1; l.in_cap = 1; l.pad = 0;
-            p.lists[nb + id] = l;
-            p.weight[nb + id] = 1;
-            p.bbpos[nb + id] = (int32_t)bbpos;
-            p.pending[nb + id] = 1;
-            pool[2u * n_ins_t + ins_idx] = prev;
-            DG_DEPART(prev, id);
-            prev = id;
-            ins_idx++;
+            if (ins_pos != bbpos) { ins_pos = bbpos; ins_id = gbase[bbpos] + Cm[(uint64_t)bbpos * K + r]; }
+            const uint32_t id = ins_id++;
+            const uint32_t rk = id - bbpos;               // bbpos backbone vertices precede group bbpos
+            DgNode nd;
+            nd.out_len = 1; nd.in_len = 1; nd.base = qb; nd.flags = 0; nd.pad = 0;
+            nd.weight = 1; nd.pending = 1;
+            nd.out_off = 3u * rk; nd.in_off = 3u * rk + 2u; nd.out_cap = 1; nd.in_cap = 1;
+            nd.bbpos = (int32_t)bbpos;
+            p.nodes[nb + id] = nd;
+            pool[3u * rk + 2u] = prev;
+            DG_DEPART(id);
+            prev = id; prev_pos = bbpos; prev_bb = false;
         }
     }
-    Am[(uint64_t)exitv * K + r] = prev + 1u;              // :106
-    DG_DEPART(prev, exitv);
+    Am[(uint64_t)exitpos * K + r] = prev + 1u;            // :106
+    DG_DEPART(bid[exitpos]);
 #undef DG_DEPART
 }
 
 // ---------------------------------------------------------------------------
-// k_lists: one wave per backbone vertex.  Row of K departures -> out list
-// [ (v+1, n) , then distinct other targets in first-read order with counts ];
-// row of K arrivals -> in list [ v-1, then distinct other sources ].
-// Distinct values are peeled off with ballot/popcount; the list under
-// construction sits in LDS so that rows longer than one wave still dedupe.
+// k_lists: one wave per backbone position.
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ int dg_lds_find(volatile int32_t *vals, int n, int x, int lane) {
     for (int b = 0; b < n; b += DG_WAVE) {
@@ -378,30 +460,49 @@ __global__ __launch_bounds__(256) void k_lists(DgParams p) {
     if (dg_failed(p) || !p.tactive[t]) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t blen = p.tlen[t];
-    const uint32_t v = blockIdx.y * 4 + wave;
-    if (v >= blen + 2) return;
+    const uint32_t pos = blockIdx.y * 4 + wave;
+    if (pos >= blen + 2) return;
     const uint32_t K = (uint32_t)(p.aln_begin[t + 1] - p.aln_begin[t]);
     const uint32_t stride = p.max_k + 2;
     volatile int32_t *vals = s_tmp + (size_t)wave * 2 * stride;
     volatile int32_t *cnts = vals + stride;
     const uint64_t nb = p.node_base[t];
+    const uint64_t bv = p.bbv_base[t];
+    const uint32_t v = p.bid[bv + pos];
     uint32_t *pool = p.pool + p.pool_base[t];
-    const uint32_t *Am = p.matA + p.mat_base[t] + (uint64_t)v * K;
-    const uint32_t *Dm = p.matD + p.mat_base[t] + (uint64_t)v * K;
-    DgLists l;
-    l.out_off = 0; l.in_off = 0; l.out_cap = 0; l.in_cap = 0; l.pad = 0;
+    const uint32_t *Am = p.matA + p.mat_base[t] + (uint64_t)pos * K;
+    const uint32_t *Dm = p.matD + p.mat_base[t] + (uint64_t)pos * K;
+    const uint32_t capb = dg_capb(K);
+    const uint32_t fixed = 3u * p.t_nins[t] + pos * 3u * capb;
+    uint32_t out_off = fixed, in_off = fixed + 2u * capb;
+    uint32_t out_cap = capb, in_cap = capb;
     uint32_t out_len = 0, in_len = 0;
+    uint32_t n_match = 0, n_cov = 0, last_base = 0;
 
     for (int dir = 0; dir < 2; dir++) {
         // dir 0: out list from departures; dir 1: in list from arrivals
-        if (dir == 0 && v == blen + 1) continue;
-        if (dir == 1 && v == 0) continue;
+        if (dir == 0 && pos == blen + 1) continue;
+        if (dir == 1 && pos == 0) continue;
         const uint32_t *row = dir == 0 ? Dm : Am;
         int n = 1;
-        if (lane == 0) { vals[0] = dir == 0 ? (int32_t)(v + 1) : (int32_t)(v - 1); cnts[0] = 0; }
+        if (lane == 0) {
+            vals[0] = dir == 0 ? (int32_t)p.bid[bv + pos + 1] : (int32_t)p.bid[bv + pos - 1];
+            cnts[0] = 0;
+        }
         for (uint32_t r0 = 0; r0 < K; r0 += DG_WAVE) {
             const uint32_t r = r0 + lane;
-            const int32_t val = r < K ? (int32_t)row[r] : 0;      // neighbour id + 1, 0 = none
+            const uint32_t cell = r < K ? row[r] : 0u;
+            int32_t val = (int32_t)cell;                       // neighbour id + 1, 0 = none
+            if (dir == 1) {
+                const uint32_t idf = DG_CELL_ID(cell);
+                const unsigned long long covered = __ballot(cell != 0u);
+                if (pos <= blen) {
+                    n_cov += (uint32_t)__popcll(covered);
+                    n_match += (uint32_t)__popcll(__ballot(cell != 0u && idf != DG_CELL_DEL));
+                    if (covered) last_base = DG_CELL_BASE(__shfl(cell, 63 - __clzll((long long)covered)));
+                }
+                val = (cell != 0u && idf != DG_CELL_DEL) ? (int32_t)idf : 0;
+            }
             unsigned long long rem = __ballot(val != 0);
             while (rem) {
                 const int first = __ffsll((long long)rem) - 1;
@@ -419,25 +520,31 @@ __global__ __launch_bounds__(256) void k_lists(DgParams p) {
             }
         }
         if (n > 65000) { if (lane == 0) dg_fail(p, DG_E_INTERNAL); return; }
-        const uint32_t cap = (uint32_t)n + 2u;
-        const uint32_t words = dir == 0 ? 2u * cap : cap;
-        const uint32_t off = dg_pool_alloc(p, t, words, lane);
-        if (off == 0xFFFFFFFFu) return;
+        uint32_t off = dir == 0 ? out_off : in_off;
+        if ((uint32_t)n > capb) {                               // rare: move to the growth region
+            const uint32_t cap = (uint32_t)n + 2u;
+            off = dg_pool_alloc(p, t, dir == 0 ? 2u * cap : cap, lane);
+            if (off == 0xFFFFFFFFu) return;
+            if (dir == 0) { out_off = off; out_cap = cap; } else { in_off = off; in_cap = cap; }
+        }
         for (int i = lane; i < n; i += DG_WAVE) {
             if (dir == 0) { pool[off + 2 * i] = (uint32_t)vals[i]; pool[off + 2 * i + 1] = (uint32_t)cnts[i]; }
             else pool[off + i] = (uint32_t)vals[i];
         }
-        if (dir == 0) { l.out_off = off; l.out_cap = (uint16_t)cap; out_len = (uint32_t)n; }
-        else { l.in_off = off; l.in_cap = (uint16_t)cap; in_len = (uint32_t)n; }
+        if (dir == 0) out_len = (uint32_t)n; else in_len = (uint32_t)n;
     }
     if (lane == 0) {
-        DgHot h = p.hot[nb + v];
-        h.out_len = (uint16_t)out_len;
-        h.in_len = (uint16_t)in_len;
-        const uint32_t vote = p.bvote[p.bbv_base[t] + v];
-        if (vote) h.base = (uint8_t)(vote & 0xff);     // last read to cover the position wins
-        p.hot[nb + v] = h;
-        p.lists[nb + v] = l;
-        p.pending[nb + v] = (int32_t)in_len;
+        DgNode nd = p.nodes[nb + v];
+        nd.out_len = (uint16_t)out_len;
+        nd.in_len = (uint16_t)in_len;
+        nd.out_off = out_off; nd.in_off = in_off;
+        nd.out_cap = (uint16_t)out_cap; nd.in_cap = (uint16_t)in_cap;
+        nd.pending = (int32_t)in_len;
+        if (pos >= 1 && pos <= blen) {
+            nd.weight = 1 + (int32_t)n_match;                   // AlnGraphBoost.cpp:81
+            if (n_cov) nd.base = (uint8_t)last_base;            // last read to cover the position (:79,:90)
+            p.cov[bv + pos] = (int32_t)n_cov;                   // :76,:87
+        }
+        p.nodes[nb + v] = nd;
     }
 }

@@ -66,17 +66,41 @@ def _check_batch(ctx_factory, batch, min_cov=0, min_len=0, trim=0, min_weight=-1
 
 
 def _oracle_graph(batch, t, min_len, trim, merge):
-    g = oracle.Graph(blen=int(batch.tlen[t])) if batch.backbone is None else oracle.Graph(
-        backbone=batch.backbone[int(batch.backbone_off[t]):int(batch.backbone_off[t]) + int(batch.tlen[t])].tobytes())
+    """Oracle graph of target t plus the oracle-id -> device-id map.  The oracle numbers
+    inserted vertices in (read, column) order after the backbone (the reference's
+    add_vertex order); the device numbers vertices in backbone-position order: the inserted
+    vertices whose _bbMap is p in (read, column) order, then backbone vertex p."""
+    blen = int(batch.tlen[t])
+    g = oracle.Graph(blen=blen) if batch.backbone is None else oracle.Graph(
+        backbone=batch.backbone[int(batch.backbone_off[t]):int(batch.backbone_off[t]) + blen].tobytes())
+    ins_pos = []
     for s, q, tt in batch.target_alignments(t):
         if len(q) < min_len:
             continue
         qn, tn = oracle.normalize_gaps(q, tt)
         qn, tn, s2 = oracle.trim_aln(qn, tn, s, trim)
         g.add_aln(s2, qn, tn)
+        bb = s2
+        for a, b in zip(qn, tn):
+            if a == b or a == 0x2D:
+                bb += 1
+            elif b == 0x2D:
+                ins_pos.append(bb)
     if merge:
         assert g.merge_nodes() == 0
-    return [(b, w, c, d, oe, [s for s, _ in ie]) for b, w, c, d, oe, ie in g.adjacency()]
+    gcount = [0] * (blen + 2)
+    for p in ins_pos:
+        gcount[p] += 1
+    gbase, acc = [], 0
+    for p in range(blen + 2):
+        gbase.append(acc)
+        acc += gcount[p] + 1
+    o2d = [gbase[p] + gcount[p] for p in range(blen + 2)]
+    seen = [0] * (blen + 2)
+    for p in ins_pos:
+        o2d.append(gbase[p] + seen[p])
+        seen[p] += 1
+    return g.adjacency(), o2d
 
 
 @pytest.mark.parametrize("merge", [False, True])
@@ -96,19 +120,21 @@ def test_graph_adjacency_matches_oracle(gpu_ctx_factory, merge):
     ctx.consensus(batch)
     for t in range(batch.n_targets):
         got = ctx.debug_graph(t)
-        exp = _oracle_graph(batch, t, 0, 2, merge)
-        assert len(got) == len(exp), f"target {t}: vertex count"
-        for v, (g, e) in enumerate(zip(got, exp)):
-            gb, gw, gc, gd, goe, gie = g
-            eb, ew, ec, ed, eoe, eie = e
-            assert gd == ed, f"target {t} vertex {v}: deleted flag"
+        exp, o2d = _oracle_graph(batch, t, 0, 2, merge)
+        assert len(got) == len(exp) == len(o2d), f"target {t}: vertex count"
+        assert sorted(o2d) == list(range(len(got)))
+        blen = int(batch.tlen[t])
+        for o, (eb, ew, ec, ed, eoe, eie) in enumerate(exp):
+            g = got[o2d[o]]
+            assert g["deleted"] == ed, f"target {t} vertex {o}: deleted flag"
+            assert g["backbone"] == (o < blen + 2)
             if ed:
                 continue
-            assert (gb, gw) == (eb, ew), f"target {t} vertex {v}: base/weight {g} vs {e}"
-            if v < int(batch.tlen[t]) + 2:
-                assert gc == ec, f"target {t} vertex {v}: coverage"
-            assert goe == eoe, f"target {t} vertex {v}: out list {goe} vs {eoe}"
-            assert gie == eie, f"target {t} vertex {v}: in list {gie} vs {eie}"
+            assert (g["base"], g["weight"]) == (eb, ew), f"target {t} vertex {o}: base/weight {g} vs {exp[o]}"
+            if o < blen + 2:
+                assert g["coverage"] == ec, f"target {t} vertex {o}: coverage"
+            assert g["out"] == [(o2d[d], c) for d, c in eoe], f"target {t} vertex {o}: out list"
+            assert g["inn"] == [o2d[s] for s, _ in eie], f"target {t} vertex {o}: in list"
 
 
 @pytest.mark.parametrize("seed", [1, 2, 3])
