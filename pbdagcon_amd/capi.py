@@ -28,6 +28,7 @@ EXPORTS = [
     "dagcon_abi_version", "dagcon_default_opts", "dagcon_create", "dagcon_destroy",
     "dagcon_last_error", "dagcon_consensus", "dagcon_upload", "dagcon_run", "dagcon_sync",
     "dagcon_fetch", "dagcon_get_timings", "dagcon_normalize", "dagcon_debug_graph",
+    "dagcon_debug_counters",
 ]
 
 
@@ -266,6 +267,12 @@ class Context:
             o, m = int(out_off[a]), int(out_len[a])
             res.append((int(out_start[a]), qout[o:o + m].tobytes(), tout[o:o + m].tobytes()))
         return res
+
+    def debug_counters(self):
+        a = (C.c_ulonglong * 8)()
+        self.L.dagcon_debug_counters.argtypes = [C.c_void_p, C.c_void_p]
+        self._chk(self.L.dagcon_debug_counters(self.h, a))
+        return list(a)
 
     def debug_graph(self, target=0):
         """Per vertex (device ids, backbone-position order):

@@ -126,7 +126,7 @@ int ensure_arenas(Ctx *c) {
     ENSURE(c, c->d_nodes, c->node_cap * sizeof(DgNode));
     ENSURE(c, c->d_best, c->node_cap * 4);
     ENSURE(c, c->d_queue, c->node_cap * 4);
-    ENSURE(c, c->d_score, c->node_cap * 4);
+    ENSURE(c, c->d_score, c->node_cap * 8);
     ENSURE(c, c->d_cns_tmp, c->node_cap);
     ENSURE(c, c->d_pool, c->pool_cap * 4);
     ENSURE(c, c->d_stk, (uint64_t)c->T * c->stk_words * 4);
@@ -167,7 +167,7 @@ void fill_params(Ctx *c, DgParams &p) {
     p.cov = (int32_t *)c->d_cov.p; p.gcount = (uint32_t *)c->d_gcount.p;
     p.gbase = (uint32_t *)c->d_gbase.p; p.bid = (uint32_t *)c->d_bid.p;
     p.nodes = (DgNode *)c->d_nodes.p; p.best = (int32_t *)c->d_best.p;
-    p.queue = (int32_t *)c->d_queue.p; p.score = (float *)c->d_score.p;
+    p.queue = (int32_t *)c->d_queue.p; p.score = (float2 *)c->d_score.p;
     p.cns_tmp = (uint8_t *)c->d_cns_tmp.p; p.node_cap = c->node_cap;
     p.pool = (uint32_t *)c->d_pool.p; p.pool_cap = c->pool_cap;
     p.stk = (int32_t *)c->d_stk.p; p.stk_words = c->stk_words; p.growth_pct = c->growth_pct;
@@ -215,8 +215,10 @@ int launch_all(Ctx *c) {
     if (c->T > 0 && !(c->opts.flags & DAGCON_FLAG_STOP_AFTER_BUILD))
         hipLaunchKernelGGL(k_merge, dim3(c->T), dim3(64), 0, s, p);
     HIPCHK(c, hipEventRecord(c->ev[3], s));
-    if (c->T > 0 && !(c->opts.flags & (DAGCON_FLAG_STOP_AFTER_BUILD | DAGCON_FLAG_STOP_AFTER_MERGE)))
+    if (c->T > 0 && !(c->opts.flags & (DAGCON_FLAG_STOP_AFTER_BUILD | DAGCON_FLAG_STOP_AFTER_MERGE))) {
+        hipLaunchKernelGGL(k_bp_prepare, dim3(c->T, 16), dim3(256), 0, s, p);
         hipLaunchKernelGGL(k_bestpath, dim3(c->T), dim3(64), 0, s, p);
+    }
     HIPCHK(c, hipEventRecord(c->ev[4], s));
     HIPCHK(c, hipGetLastError());
     return DAGCON_OK;
@@ -508,6 +510,18 @@ int dagcon_fetch(dagcon_ctx *ctx, dagcon_results *res) {
     res->seq_off = c->r_seq_off.data(); res->seq_len = c->r_seq_len.data();
     res->seq_blob = c->r_blob.data(); res->seq_bytes = nb;
     c->fetched = true;
+    return DAGCON_OK;
+}
+
+// diagnostic builds (-DDG_STAMPS) only: raw device counters of the last run
+int dagcon_debug_counters(dagcon_ctx *ctx, unsigned long long *out8) {
+    if (!ctx || !out8) return DAGCON_ERR_INVALID_ARG;
+    Ctx *c = reinterpret_cast<Ctx *>(ctx);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    DgStatus st;
+    HIPCHK(c, hipMemcpy(&st, c->d_st.p, sizeof st, hipMemcpyDeviceToHost));
+    for (int i = 0; i < 8; i++) out8[i] = st.dbg[i];
     return DAGCON_OK;
 }
 

@@ -14,6 +14,7 @@
 // and the reverse sweep of bestPath walk memory monotonically (cache lines are reused, not
 // re-fetched), which is what a latency-bound pointer chase needs.
 #pragma once
+#include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #define DG_GAP '-'
@@ -45,6 +46,7 @@ struct DgStatus {
     unsigned long long cns_top;    // bump cursor into the consensus blob
     unsigned long long seg_top;    // bump cursor into the segment arrays
     unsigned long long n_columns;  // normalised, trimmed columns
+    unsigned long long dbg[8];     // diagnostic build only (DG_STAMPS): cycle / visit counters of target 0
 };
 
 // One 32-byte record per vertex.  The first 16 bytes are what a neighbour needs to know
@@ -111,7 +113,7 @@ struct DgParams {
     // ---- vertex arena ----
     DgNode *nodes;
     int32_t *best, *queue;
-    float *score;
+    float2 *score;                 // (best-path score, edge-score term of the vertex as a target)
     uint8_t *cns_tmp;
     uint64_t node_cap;
     uint32_t *pool;

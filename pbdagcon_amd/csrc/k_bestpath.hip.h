@@ -5,16 +5,48 @@
 // ORDER with strict '>' (first maximum wins, :411), of
 //     score[t] - 10                          if t.backbone && t.weight == 1
 //     count(e) - coverage[bbMap[t]]*0.5 + score[t]   otherwise          (:404-409)
-// so any reverse-topological order gives the reference's scores.  One wave
-// per target sweeps the DAG as a wavefront: every lane takes one vertex whose
-// successors are all scored, scores it, then releases its predecessors
-// (Kahn's algorithm run 64 vertices at a time).  fp32 throughout; every value
-// is a multiple of 0.5 below 2^23, so the arithmetic is exact and the
-// expression order of the reference is kept (-ffp-contract=off).
+// so any reverse-topological order gives the reference's scores.
+//
+//   k_bp_prepare  thread per vertex: the per-target term of the edge score
+//                 (pen = coverage[bbMap[t]]*0.5, or the "-10" marker), score = 0
+//                 (std::map default), pending = out-degree
+//   k_bestpath    wave per target: Kahn sweep from the exit vertex, one vertex per
+//                 step, one list entry per lane (out entries on lanes 0-31, in
+//                 entries on lanes 32-63): gather (score, pen) of the successors,
+//                 wave max with lowest-lane tie-break (= first maximum in list
+//                 order), release the predecessors with plain stores (one wave
+//                 owns the target, no atomics); then the best-edge walk and the
+//                 segmentation.
+//
+// fp32 throughout; every value is a multiple of 0.5 below 2^23, so the
+// arithmetic is exact and the expression order of the reference is kept
+// (-ffp-contract=off).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <float.h>
 #include "dagcon_dev.h"
+
+#define DG_PEN_BACKBONE_ONLY (-1.0f)    // real penalties are >= 0
+
+__global__ __launch_bounds__(256) void k_bp_prepare(DgParams p) {
+    const uint32_t t = blockIdx.x;
+    if (dg_failed(p) || !p.tactive[t]) return;
+    const uint64_t nb = p.node_base[t];
+    const uint32_t N = p.n_nodes[t];
+    const int32_t *cov = p.cov + p.bbv_base[t];
+    for (uint32_t v = blockIdx.y * 256 + threadIdx.x; v < N; v += gridDim.y * 256) {
+        DgNode *n = &p.nodes[nb + v];
+        const uint4 h = *reinterpret_cast<const uint4 *>(n);
+        const uint4 h2 = *(reinterpret_cast<const uint4 *>(n) + 1);
+        const uint32_t flags = (h.y >> 8) & 0xffu;
+        float pen;
+        if ((flags & DG_NF_BACKBONE) && (int)h.z == 1) pen = DG_PEN_BACKBONE_ONLY;   // :404
+        else pen = (float)cov[(int)h2.w] * 0.5f;                                      // :407-408
+        n->pending = (int)(h.x & 0xffffu);         // out-edges not yet visited (:423-439)
+        p.score[nb + v] = make_float2(0.0f, pen);  // std::map<VtxDesc,float>: absent key reads as 0
+        p.best[nb + v] = -1;
+    }
+}
 
 __global__ __launch_bounds__(64) void k_bestpath(DgParams p) {
     const uint32_t t = blockIdx.x;
@@ -24,63 +56,83 @@ __global__ __launch_bounds__(64) void k_bestpath(DgParams p) {
     DgNode *nd = p.nodes + nb;
     int32_t *best = p.best + nb;
     int32_t *queue = p.queue + nb;
-    float *score = p.score + nb;
-    const int32_t *cov = p.cov + p.bbv_base[t];
+    float2 *score = p.score + nb;
     const uint32_t *pool = p.pool + p.pool_base[t];
     const uint32_t N = p.n_nodes[t];
     const int exitv = (int)N - 1;
-    __shared__ uint32_t s_qt;
 
-    for (uint32_t v = lane; v < N; v += 64) {
-        nd[v].pending = nd[v].out_len;   // out-edges not yet visited (:423-439)
-        best[v] = -1;
-        score[v] = 0.0f;              // std::map<VtxDesc,float>: absent key reads as 0
-    }
-    if (lane == 0) { queue[0] = exitv; s_qt = 1; }
+    if (lane == 0) queue[0] = exitv;
     __syncthreads();
     uint32_t qh = 0, qt = 1;
+    bool bad = false;
     while (qh < qt) {
-        const uint32_t m = min(64u, qt - qh);
-        int n = -1;
-        if ((uint32_t)lane < m) {
-            n = queue[qh + lane];
-            const uint32_t off = nd[n].out_off;
-            const int len = nd[n].out_len;
-            float bs = -FLT_MAX;
-            int bd = -1;
-            for (int i = 0; i < len; i++) {
-                const int d = (int)pool[off + 2 * i];
-                const int cnt = (int)pool[off + 2 * i + 1];
-                const DgNode h = nd[d];
-                const float s = score[d];
-                float ns;
-                if ((h.flags & DG_NF_BACKBONE) && h.weight == 1) {
-                    ns = s - 10.0f;
+        const int n = queue[qh++];
+        const DgNode nn = nd[n];
+        const int out_len = nn.out_len, in_len = nn.in_len;
+        if (out_len <= 32 && in_len <= 32) {
+            const bool is_out = lane < 32;
+            const int idx = lane & 31;
+            const bool valid = is_out ? idx < out_len : idx < in_len;
+            int nbr = 0, cnt = 0;
+            if (valid) {
+                if (is_out) { nbr = (int)pool[nn.out_off + 2 * idx]; cnt = (int)pool[nn.out_off + 2 * idx + 1]; }
+                else nbr = (int)pool[nn.in_off + idx];
+            }
+            float ns = -FLT_MAX;
+            int pend = 0;
+            if (valid) {
+                if (is_out) {
+                    const float2 sp = score[nbr];
+                    if (sp.y == DG_PEN_BACKBONE_ONLY) ns = sp.x - 10.0f;
+                    else ns = (float)cnt - sp.y + sp.x;
                 } else {
-                    const int c = cov[h.bbpos];
-                    ns = (float)cnt - (float)c * 0.5f + s;
-                }
-                if (ns > bs) { bs = ns; bd = d; }
-            }
-            if (bd >= 0) { score[n] = bs; best[n] = bd; }
-        }
-        __syncthreads();              // scores of this wavefront land before anyone is released
-        if (n >= 0) {
-            const uint32_t off = nd[n].in_off;
-            const int len = nd[n].in_len;
-            for (int i = 0; i < len; i++) {
-                const int s = (int)pool[off + i];
-                if (atomicSub(&nd[s].pending, 1) == 1) {
-                    const uint32_t pos = atomicAdd(&s_qt, 1u);
-                    if (pos < N) queue[pos] = s;
+                    pend = nd[nbr].pending - 1;
+                    nd[nbr].pending = pend;
                 }
             }
+            // first maximum in list order: wave max, then the lowest lane that holds it
+            float mx = ns;
+            for (int o = 16; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+            mx = __shfl(mx, 0);                              // lanes 0-31 agree; take their value
+            const unsigned long long hit = __ballot(valid && is_out && ns == mx);
+            if (out_len > 0) {
+                const int bl = __ffsll((long long)hit) - 1;
+                const int bd = __shfl(nbr, bl);
+                if (lane == 0) { score[n].x = mx; best[n] = bd; }
+            }
+            const unsigned long long rm = __ballot(valid && !is_out && pend == 0);
+            if (valid && !is_out && pend == 0) {
+                const uint32_t pos = qt + (uint32_t)__popcll(rm & ((1ull << lane) - 1ull));
+                if (pos < N) queue[pos] = nbr;
+            }
+            qt += (uint32_t)__popcll(rm);
+        } else {
+            // a list longer than half a wave: literal loops on lane 0
+            uint32_t nqt = qt;
+            if (lane == 0) {
+                float bs = -FLT_MAX;
+                int bd = -1;
+                for (int i = 0; i < out_len; i++) {
+                    const int d = (int)pool[nn.out_off + 2 * i];
+                    const int c = (int)pool[nn.out_off + 2 * i + 1];
+                    const float2 sp = score[d];
+                    const float ns = sp.y == DG_PEN_BACKBONE_ONLY ? sp.x - 10.0f : (float)c - sp.y + sp.x;
+                    if (ns > bs) { bs = ns; bd = d; }
+                }
+                if (bd >= 0) { score[n].x = bs; best[n] = bd; }
+                for (int i = 0; i < in_len; i++) {
+                    const int s = (int)pool[nn.in_off + i];
+                    const int pend = nd[s].pending - 1;
+                    nd[s].pending = pend;
+                    if (pend == 0 && nqt < N) queue[nqt++] = s;
+                }
+            }
+            __syncthreads();
+            qt = (uint32_t)__shfl((int)nqt, 0);
         }
-        __syncthreads();
-        qh += m;
-        qt = s_qt;
-        if (qt > N) { if (lane == 0) dg_fail(p, DG_E_INTERNAL); return; }
+        if (qt > N) { bad = true; break; }
     }
+    if (bad) { if (lane == 0) dg_fail(p, DG_E_INTERNAL); return; }
 
     // :443-456 walk the best edges from enter; :327-373 segmentation.  The walk
     // is a pointer chase; lane 0 does it and keeps the consensus in cns_tmp.
@@ -98,11 +150,12 @@ __global__ __launch_bounds__(64) void k_bestpath(DgParams p) {
         uint32_t nseg = 0, steps = 0;
         bool ovf = false;
         for (;;) {
-            const DgNode h = nd[v];
+            const uint4 h = *reinterpret_cast<const uint4 *>(&nd[v]);
             const int nxt = best[v];
-            if (!(h.base == eb || h.base == xb)) {
-                tmp[idx] = h.base;
-                const int w = h.weight;
+            const uint8_t base = (uint8_t)(h.y & 0xffu);
+            if (!(base == eb || base == xb)) {
+                tmp[idx] = base;
+                const int w = (int)h.z;
                 if (!met && w >= minw) { offs = idx; met = true; }
                 else if (met && w < minw) {
                     met = false;

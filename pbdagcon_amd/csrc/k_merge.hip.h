@@ -7,15 +7,19 @@
 // the reference's order, one wave per target; parallelism across the chip
 // comes from the targets in flight, and inside a visit from the 64 lanes:
 //
-//   * a visit gathers the records of all in- and out-neighbours of the
-//     dequeued vertex at once (lanes 0-31 in-entries, lanes 32-63 out-entries)
-//     and decides with ballots whether any merge group exists; when none does
-//     (the common case) the FIFO bookkeeping of AlnGraphBoost.cpp:143-158 is
-//     done by the out lanes in one step (pending counters, ballot-ranked queue
-//     positions);
-//   * a visit that has merge work, or lists longer than 32, takes the
-//     reference-literal single-lane path below (mergeInNodes with its recursion
-//     made explicit, mergeOutNodes), on the same ordered slot lists.
+//   * a visit gathers the records of all in- (then out-) neighbours of the
+//     dequeued vertex at once, one list entry per lane, and picks the next merge
+//     group with ballots (smallest base shared by >= 2 eligible neighbours);
+//   * a group is merged cooperatively (dgw_merge_in_group / dgw_merge_out_group):
+//     the victims' edges are flattened onto lanes, deduplicated in first-
+//     occurrence order with ballot / popcount, and every list that changes is
+//     rewritten by one compaction; after a group the vertex is re-evaluated
+//     from the live graph (groups already merged are gone, no new group can
+//     form, so this equals the reference's frozen candidate lists);
+//   * the FIFO bookkeeping of AlnGraphBoost.cpp:143-158 is one step for all
+//     out-edges (pending counters, ballot-ranked queue positions);
+//   * lists longer than a wave take the reference-literal single-lane path
+//     (dgg_*), on the same ordered slot lists.
 //
 // All list primitives keep the container semantics of
 // boost::adjacency_list<vecS,vecS,bidirectionalS> (append on add_edge, stable
@@ -305,18 +309,326 @@ __device__ inline void dgg_merge_out(DgGraph &g, int n) {
     }
 }
 
-// ---- mergeNodes (AlnGraphBoost.cpp:129-160): one wave per target ------------
-__device__ __forceinline__ bool dg_has_group(unsigned long long cand, uint32_t base) {
-    // does any base occur twice among the candidate lanes?
+// ============================================================================
+// Wave-cooperative merge.  Everything below is executed by all 64 lanes with
+// wave-uniform control flow; a lane holds one list entry.
+// ============================================================================
+#define DG_LT(lane) ((1ull << (lane)) - 1ull)
+
+__device__ __forceinline__ uint4 dg_lo16(const DgNode *n) { return *reinterpret_cast<const uint4 *>(n); }
+__device__ __forceinline__ uint4 dg_hi16(const DgNode *n) { return *(reinterpret_cast<const uint4 *>(n) + 1); }
+// fields of the two halves of a DgNode
+#define DG_H_OUTLEN(h) ((int)((h).x & 0xffffu))
+#define DG_H_INLEN(h)  ((int)((h).x >> 16))
+#define DG_H_BASE(h)   ((int)((h).y & 0xffu))
+#define DG_H_WEIGHT(h) ((int)(h).z)
+#define DG_H_PEND(h)   ((int)(h).w)
+#define DG_H2_OUTOFF(h) ((h).x)
+#define DG_H2_INOFF(h)  ((h).y)
+#define DG_H2_OUTCAP(h) ((int)((h).z & 0xffffu))
+#define DG_H2_INCAP(h)  ((int)((h).z >> 16))
+
+__device__ __forceinline__ int dg_wave_incl_scan(int v, int lane) {
+    for (int o = 1; o < 64; o <<= 1) {
+        const int up = __shfl_up(v, o);
+        if (lane >= o) v += up;
+    }
+    return v;
+}
+__device__ __forceinline__ int dg_wave_sum_masked(int v, unsigned long long m) {
+    int acc = 0;
+    while (m) {
+        const int f = __ffsll((long long)m) - 1;
+        acc += __shfl(v, f);
+        m &= m - 1ull;
+    }
+    return acc;
+}
+
+// smallest base > last that at least two candidate lanes share; returns the
+// base (or 256) and the mask of its lanes
+__device__ __forceinline__ int dg_pick_group(unsigned long long cand, int base, int last, int lane,
+                                             unsigned long long *mask) {
+    int best = 256;
+    unsigned long long bm = 0;
     while (cand) {
         const int f = __ffsll((long long)cand) - 1;
-        const uint32_t b = (uint32_t)__shfl((int)base, f);
-        const unsigned long long same = __ballot(((cand >> (threadIdx.x & 63)) & 1ull) && base == b);
-        if (__popcll(same) >= 2) return true;
+        const int b = __shfl(base, f);
+        const unsigned long long same = __ballot(((cand >> lane) & 1ull) && base == b);
+        if (b > last && b < best && __popcll(same) >= 2) { best = b; bm = same; }
         cand &= ~same;
     }
-    return false;
+    *mask = bm;
+    return best;
 }
+
+__device__ __forceinline__ uint32_t dg_wave_alloc(DgGraph &g, uint32_t words, int lane) {
+    uint32_t off = 0;
+    if (lane == 0) off = dgg_alloc(g, words);
+    off = (uint32_t)__shfl((int)off, 0);
+    if (off == 0xFFFFFFFFu) g.err = true;                // every lane: keeps control flow uniform
+    return off;
+}
+
+// Removes from in[v] every source listed in vic[0..k) (stable), then appends
+// `app` when app >= 0.  pend_delta is added to v's pending counter.
+// Requires in_len(v) <= 64.
+__device__ inline void dgw_in_rewrite(DgGraph &g, int v, const volatile int *vic, int k, int app,
+                                      int pend_delta, int lane) {
+    const uint4 h = dg_lo16(&g.nd[v]), h2 = dg_hi16(&g.nd[v]);
+    const int len = DG_H_INLEN(h);
+    uint32_t off = DG_H2_INOFF(h2);
+    int cap = DG_H2_INCAP(h2);
+    int e = -1;
+    if (lane < len) e = (int)g.pool[off + lane];
+    bool rm = false;
+    for (int q = 0; q < k; q++) rm |= (e == vic[q]);
+    const bool keep = lane < len && !rm;
+    const unsigned long long km = __ballot(keep);
+    int nlen = __popcll(km);
+    const int nidx = __popcll(km & DG_LT(lane));
+    if (app >= 0 && nlen + 1 > cap) {
+        uint32_t ncap = 2u * (uint32_t)(nlen + 1);
+        if (ncap < 4) ncap = 4;
+        const uint32_t noff = dg_wave_alloc(g, ncap, lane);
+        if (noff == 0xFFFFFFFFu) return;
+        off = noff; cap = (int)ncap;
+    }
+    if (keep) g.pool[off + nidx] = (uint32_t)e;
+    if (app >= 0) { if (lane == 0) g.pool[off + nlen] = (uint32_t)app; nlen++; }
+    if (lane == 0) {
+        DgNode *n = &g.nd[v];
+        n->in_len = (uint16_t)nlen; n->in_off = off; n->in_cap = (uint16_t)cap;
+        if (pend_delta) n->pending = DG_H_PEND(h) + pend_delta;
+    }
+}
+
+// ---- mergeOutNodes, one group (AlnGraphBoost.cpp:229-266) ---------------------
+// Lanes 32..63 hold u's out entries: d (target), cnt, h (first half of the
+// target's record).  M = lanes of the group (survivor = lowest lane).
+// Returns false, with nothing modified, when a list involved is longer than a wave.
+__device__ inline bool dgw_merge_out_group(DgGraph &g, int u, const DgNode &nu, unsigned long long M,
+                                           int d, int cnt, uint4 h, bool valid_out, int lane,
+                                           volatile int *s_vic) {
+    const int an_lane = __ffsll((long long)M) - 1;
+    const unsigned long long vm = M & ~(1ull << an_lane);
+    const int an = __shfl(d, an_lane);
+    const int k = __popcll(vm);
+    const bool member = (M >> lane) & 1ull;
+    uint4 h2 = make_uint4(0, 0, 0, 0);
+    if (member) h2 = dg_hi16(&g.nd[d]);
+    // members' out entries flattened onto lanes 0..L-1: survivor's first, then victims in order
+    const int my_len = member ? DG_H_OUTLEN(h) : 0;
+    const int incl = dg_wave_incl_scan(my_len, lane);
+    const int L = __shfl(incl, 63);
+    if (L > 64) return false;
+    const int my_start = incl - my_len;
+    int src = -1, e = 0;
+    {
+        unsigned long long mm = M;
+        while (mm) {
+            const int ml = __ffsll((long long)mm) - 1;
+            mm &= mm - 1ull;
+            const int ms = __shfl(my_start, ml), mlen = __shfl(my_len, ml);
+            if (lane >= ms && lane < ms + mlen) { src = ml; e = lane - ms; }
+        }
+    }
+    const bool fl = lane < L;
+    const uint32_t src_off = (uint32_t)__shfl((int)DG_H2_OUTOFF(h2), src < 0 ? 0 : src);
+    int n2 = -1, c2 = 0;
+    if (fl) { n2 = (int)g.pool[src_off + 2 * e]; c2 = (int)g.pool[src_off + 2 * e + 1]; }
+    const bool vic_entry = fl && src != an_lane;
+    uint4 hn2 = make_uint4(0, 0, 0, 0);
+    if (vic_entry) hn2 = dg_lo16(&g.nd[n2]);
+    if (__ballot(vic_entry && DG_H_INLEN(hn2) > 64)) return false;
+
+    // ---- nothing has been modified up to here ----
+    if (vm >> lane & 1ull) s_vic[__popcll(vm & DG_LT(lane))] = d;
+    // :236-243 count(u->an) += counts of u->victims, weight[an] += weights
+    const int add_cnt = dg_wave_sum_masked(cnt, vm);
+    const int add_w = dg_wave_sum_masked(DG_H_WEIGHT(h), vm);
+    // :246-265 fold the victims' out edges into the survivor's, first occurrence order
+    unsigned long long rem = __ballot(fl), first_m = 0;
+    int newcnt = c2;
+    while (rem) {
+        const int f = __ffsll((long long)rem) - 1;
+        const int x = __shfl(n2, f);
+        const unsigned long long same = __ballot(fl && n2 == x);
+        rem &= ~same;
+        first_m |= 1ull << f;
+        const int tot = dg_wave_sum_masked(c2, same);
+        if (lane == f) newcnt = tot;
+        const unsigned long long vsame = same & __ballot(vic_entry);
+        const int nv = __popcll(vsame);
+        if (nv) {
+            const bool is_new = (vsame >> f) & 1ull;       // survivor had no edge to x
+            dgw_in_rewrite(g, x, s_vic, k, is_new ? an : -1, -(nv - (is_new ? 1 : 0)), lane);
+            if (g.err) return true;
+        }
+    }
+    // survivor's new out list
+    {
+        const int nlen = __popcll(first_m);
+        uint32_t off = (uint32_t)__shfl((int)DG_H2_OUTOFF(h2), an_lane);
+        int cap = __shfl(DG_H2_OUTCAP(h2), an_lane);
+        if (nlen > cap) {
+            uint32_t ncap = 2u * (uint32_t)(nlen + 1);
+            if (ncap < 4) ncap = 4;
+            const uint32_t noff = dg_wave_alloc(g, 2u * ncap, lane);
+            if (noff == 0xFFFFFFFFu) return true;
+            off = noff; cap = (int)ncap;
+        }
+        if ((first_m >> lane) & 1ull) {
+            const int idx = __popcll(first_m & DG_LT(lane));
+            g.pool[off + 2 * idx] = (uint32_t)n2;
+            g.pool[off + 2 * idx + 1] = (uint32_t)newcnt;
+        }
+        const int an_w = __shfl(DG_H_WEIGHT(h), an_lane);   // all lanes: a shuffle under a divergent branch reads 0
+        if (lane == 0) {
+            DgNode *a = &g.nd[an];
+            a->out_len = (uint16_t)nlen; a->out_off = off; a->out_cap = (uint16_t)cap;
+            a->weight = an_w + add_w;
+        }
+    }
+    // u's out list without the victims (stable), survivor's edge count updated
+    {
+        const bool keep = valid_out && !((vm >> lane) & 1ull);
+        const unsigned long long km = __ballot(keep);
+        if (keep) {
+            const int idx = __popcll(km & DG_LT(lane));
+            g.pool[nu.out_off + 2 * idx] = (uint32_t)d;
+            g.pool[nu.out_off + 2 * idx + 1] = (uint32_t)(lane == an_lane ? cnt + add_cnt : cnt);
+        }
+        if (lane == 0) g.nd[u].out_len = (uint16_t)__popcll(km);
+    }
+    // AlnGraphBoost.cpp:269-273 for every victim
+    if ((vm >> lane) & 1ull) {
+        DgNode *vn = &g.nd[d];
+        vn->out_len = 0; vn->in_len = 0; vn->flags |= DG_NF_DELETED;
+    }
+    return true;
+}
+
+// ---- mergeInNodes, one group (AlnGraphBoost.cpp:176-212) ----------------------
+// Lanes 0..31 hold n's in entries: s (source), h (first half of its record).
+// M = lanes of the group (survivor = lowest lane).  *an_out = survivor.
+// Returns false, with nothing modified, when a list involved is longer than a wave.
+__device__ inline bool dgw_merge_in_group(DgGraph &g, int n, const DgNode &nn, unsigned long long M,
+                                          int s, uint4 h, bool valid_in, int lane,
+                                          volatile int *s_vic, int *an_out) {
+    const int an_lane = __ffsll((long long)M) - 1;
+    const unsigned long long vm = M & ~(1ull << an_lane);
+    const int an = __shfl(s, an_lane);
+    *an_out = an;
+    const int k = __popcll(vm);
+    const bool member = (M >> lane) & 1ull;
+    const bool victim = (vm >> lane) & 1ull;
+    uint4 h2 = make_uint4(0, 0, 0, 0);
+    if (member) h2 = dg_hi16(&g.nd[s]);
+    int c0 = 0;
+    if (member) c0 = (int)g.pool[DG_H2_OUTOFF(h2) + 1];     // count of its single out edge (-> n)
+    // victims' in entries flattened onto lanes 0..L-1, victims in order
+    const int my_len = victim ? DG_H_INLEN(h) : 0;
+    const int incl = dg_wave_incl_scan(my_len, lane);
+    const int L = __shfl(incl, 63);
+    if (L > 64) return false;
+    const int my_start = incl - my_len;
+    int src = -1, e = 0;
+    {
+        unsigned long long mm = vm;
+        while (mm) {
+            const int ml = __ffsll((long long)mm) - 1;
+            mm &= mm - 1ull;
+            const int ms = __shfl(my_start, ml), mlen = __shfl(my_len, ml);
+            if (lane >= ms && lane < ms + mlen) { src = ml; e = lane - ms; }
+        }
+    }
+    const bool fl = lane < L;
+    const uint32_t src_off = (uint32_t)__shfl((int)DG_H2_INOFF(h2), src < 0 ? 0 : src);
+    int n1 = -1;
+    if (fl) n1 = (int)g.pool[src_off + e];
+    uint4 hn1 = make_uint4(0, 0, 0, 0);
+    if (fl) hn1 = dg_lo16(&g.nd[n1]);
+    if (__ballot(fl && DG_H_OUTLEN(hn1) > 64)) return false;
+
+    // ---- nothing has been modified up to here ----
+    if (victim) s_vic[__popcll(vm & DG_LT(lane))] = s;
+    // :183-190 survivor's out edge count and weight
+    const int add_cnt = dg_wave_sum_masked(c0, vm);
+    const int add_w = dg_wave_sum_masked(DG_H_WEIGHT(h), vm);
+    if (lane == an_lane) {
+        g.pool[DG_H2_OUTOFF(h2) + 1] = (uint32_t)(c0 + add_cnt);
+        g.nd[an].weight = DG_H_WEIGHT(h) + add_w;
+    }
+    // :193-212 re-point the victims' in edges to the survivor, in order
+    uint32_t a_in_off = (uint32_t)__shfl((int)DG_H2_INOFF(h2), an_lane);
+    int a_in_cap = __shfl(DG_H2_INCAP(h2), an_lane);
+    int a_in_len = __shfl(DG_H_INLEN(h), an_lane);
+    bool a_dirty = false;
+    unsigned long long rem = __ballot(fl);
+    while (rem) {
+        const int f = __ffsll((long long)rem) - 1;
+        const int x = __shfl(n1, f);
+        rem &= ~__ballot(fl && n1 == x);
+        // out[x]: drop the entries that point at victims, fold their counts into x->an
+        const uint4 hx2 = dg_hi16(&g.nd[x]);
+        const int xlen = __shfl(DG_H_OUTLEN(hn1), f);
+        const uint32_t xoff = DG_H2_OUTOFF(hx2);
+        int dst = -1, c = 0;
+        if (lane < xlen) { dst = (int)g.pool[xoff + 2 * lane]; c = (int)g.pool[xoff + 2 * lane + 1]; }
+        bool isv = false;
+        for (int q = 0; q < k; q++) isv |= (dst == s_vic[q]);
+        const unsigned long long vmask = __ballot(lane < xlen && isv);
+        const int csum = dg_wave_sum_masked(c, vmask);
+        const unsigned long long apos = __ballot(lane < xlen && dst == an);
+        const bool keep = lane < xlen && !isv;
+        const unsigned long long km = __ballot(keep);
+        int nlen = __popcll(km);
+        if (keep) {
+            const int idx = __popcll(km & DG_LT(lane));
+            g.pool[xoff + 2 * idx] = (uint32_t)dst;
+            g.pool[xoff + 2 * idx + 1] = (uint32_t)(((apos >> lane) & 1ull) ? c + csum : c);
+        }
+        if (!apos) {
+            // new edge x->an: END of out[x] (room is there: at least one entry was dropped)
+            if (lane == 0) { g.pool[xoff + 2 * nlen] = (uint32_t)an; g.pool[xoff + 2 * nlen + 1] = (uint32_t)csum; }
+            nlen++;
+            // ... and END of in[an]
+            if (a_in_len + 1 > a_in_cap) {
+                uint32_t ncap = 2u * (uint32_t)(a_in_len + 1);
+                if (ncap < 4) ncap = 4;
+                const uint32_t noff = dg_wave_alloc(g, ncap, lane);
+                if (noff == 0xFFFFFFFFu) return true;
+                if (lane < a_in_len) g.pool[noff + lane] = g.pool[a_in_off + lane];
+                for (int i = 64 + lane; i < a_in_len; i += 64) g.pool[noff + i] = g.pool[a_in_off + i];
+                a_in_off = noff; a_in_cap = (int)ncap;
+            }
+            if (lane == 0) g.pool[a_in_off + a_in_len] = (uint32_t)x;
+            a_in_len++;
+            a_dirty = true;
+        }
+        if (lane == 0) g.nd[x].out_len = (uint16_t)nlen;
+    }
+    if (a_dirty && lane == 0) {
+        DgNode *a = &g.nd[an];
+        a->in_len = (uint16_t)a_in_len; a->in_off = a_in_off; a->in_cap = (uint16_t)a_in_cap;
+    }
+    // in[n] without the victims (stable)
+    {
+        const bool keep = valid_in && !victim;
+        const unsigned long long km = __ballot(keep);
+        if (keep) g.pool[nn.in_off + __popcll(km & DG_LT(lane))] = (uint32_t)s;
+        if (lane == 0) g.nd[n].in_len = (uint16_t)__popcll(km);
+    }
+    if (victim) {
+        DgNode *vn = &g.nd[s];
+        vn->out_len = 0; vn->in_len = 0; vn->flags |= DG_NF_DELETED;
+    }
+    return true;
+}
+
+// ---- mergeNodes (AlnGraphBoost.cpp:129-160): one wave per target ------------
+#define DG_IN_STACK 48
 
 __global__ __launch_bounds__(64) void k_merge(DgParams p) {
     const uint32_t t = blockIdx.x;
@@ -329,51 +641,113 @@ __global__ __launch_bounds__(64) void k_merge(DgParams p) {
     g.stk = p.stk + (uint64_t)t * p.stk_words; g.stk_words = p.stk_words;
     g.st = p.st; g.t = t; g.err = false;
     const uint32_t N = p.n_nodes[t];
+    __shared__ int s_vic[64];
+    __shared__ int s_stk[2 * DG_IN_STACK];
     uint32_t qh = 0, qt = 1;
     if (lane == 0) g.queue[0] = 0;                       // enter vertex
     __syncthreads();
     int failed = 0;
+#ifdef DG_STAMPS
+    unsigned long long c_fast = 0, c_slow = 0, n_fast = 0, n_slow = 0, n_scalar = 0, t_prev = clock64();
+#endif
     while (qh < qt && !failed) {
         const int u = g.queue[qh++];
-        const DgNode nu = g.nd[u];
-        const int in_len = nu.in_len, out_len = nu.out_len;
-        bool slow = in_len > 32 || out_len > 32;
-        if (!slow) {
-            const bool is_in = lane < 32;
-            const int idx = lane & 31;
-            const bool valid = is_in ? idx < in_len : idx < out_len;
-            int nbr = 0;
-            if (valid) nbr = (int)(is_in ? g.pool[nu.in_off + idx] : g.pool[nu.out_off + 2 * idx]);
+        bool scalar = false, merged = false;
+
+        // ---------------- mergeInNodes(u), recursion on an explicit stack ----------------
+        int sp = 1;
+        int fr_n = u, fr_last = -1;                       // top frame lives in registers
+        while (sp > 0) {
+            const DgNode nn = g.nd[fr_n];
+            if (nn.in_len > 32) { scalar = true; break; }
+            const bool valid = lane < nn.in_len;
+            int s = 0;
+            if (valid) s = (int)g.pool[nn.in_off + lane];
             uint4 h = make_uint4(0, 0, 0, 0);
-            if (valid) h = *reinterpret_cast<const uint4 *>(&g.nd[nbr]);   // lens, base, weight, pending
-            const uint32_t n_out = h.x & 0xffffu, n_in = h.x >> 16, base = h.y & 0xffu;
-            const bool elig = valid && (is_in ? n_out == 1u : n_in == 1u);
-            const unsigned long long em = __ballot(elig);
-            const unsigned long long em_in = em & 0xffffffffull, em_out = em & ~0xffffffffull;
-            bool work = false;
-            if (__popcll(em_in) >= 2) work = dg_has_group(em_in, base);
-            if (!work && __popcll(em_out) >= 2) work = dg_has_group(em_out, base);
-            if (work) slow = true;
-            else {
-                // AlnGraphBoost.cpp:143-158: mark out-edges visited, enqueue targets
-                // whose in-edges are now all visited, in out-list order
-                const bool outl = valid && !is_in;
-                const int pend = (int)h.w - 1;
-                if (outl) g.nd[nbr].pending = pend;
-                const unsigned long long rm = __ballot(outl && pend == 0);
-                if (outl && pend == 0) {
-                    const uint32_t pos = qt + (uint32_t)__popcll(rm & ((1ull << lane) - 1ull));
-                    if (pos < N) g.queue[pos] = nbr;
-                }
-                qt += (uint32_t)__popcll(rm);
-                if (qt > N) { if (lane == 0) dgg_fail(g, DG_E_INTERNAL); failed = 1; }
+            if (valid) h = dg_lo16(&g.nd[s]);
+            const unsigned long long cand = __ballot(valid && DG_H_OUTLEN(h) == 1);
+            unsigned long long M = 0;
+            int b = 256;
+            if (__popcll(cand) >= 2) b = dg_pick_group(cand, DG_H_BASE(h), fr_last, lane, &M);
+            if (b == 256) {                               // frame done: pop
+                sp--;
+                if (sp > 0) { fr_n = s_stk[2 * (sp - 1)]; fr_last = s_stk[2 * (sp - 1) + 1]; }
+                continue;
             }
+            if (sp >= DG_IN_STACK) { scalar = true; break; }
+            int an = -1;
+            if (!dgw_merge_in_group(g, fr_n, nn, M, s, h, valid, lane, s_vic, &an)) { scalar = true; break; }
+            merged = true;
+            if (g.err) break;
+            fr_last = b;
+            if (lane == 0) { s_stk[2 * (sp - 1)] = fr_n; s_stk[2 * (sp - 1) + 1] = fr_last; }
+            sp++;                                         // :213 recurse on the survivor
+            fr_n = an; fr_last = -1;
         }
-        if (slow) {
+        if (scalar && !g.err) {
+            // finish every open frame, deepest first, on the reference-literal path;
+            // groups already merged are gone, so re-evaluating a frame from scratch is exact
+            if (lane == 0) {
+                dgg_merge_in(g, fr_n);
+                for (int f = sp - 2; f >= 0 && !g.err; f--) dgg_merge_in(g, s_stk[2 * f]);
+            }
+            __syncthreads();
+            g.err = __any((int)g.err);
+        }
+
+        // ---------------- mergeOutNodes(u) + FIFO bookkeeping ----------------
+        bool done = false;
+        if (scalar) {
+            if (lane == 0 && !g.err) dgg_merge_out(g, u);
+            __syncthreads();
+            g.err = __any((int)g.err);
+        }
+        int last_out = -1;
+        while (!done && !g.err) {
+            const DgNode nu = g.nd[u];
+            const int out_len = nu.out_len;
+            if (out_len > 64) break;                      // bookkeeping by the single-lane loop below
+            const bool valid = lane < out_len;
+            int d = 0, cnt = 0;
+            if (valid) { d = (int)g.pool[nu.out_off + 2 * lane]; cnt = (int)g.pool[nu.out_off + 2 * lane + 1]; }
+            uint4 h = make_uint4(0, 0, 0, 0);
+            if (valid) h = dg_lo16(&g.nd[d]);
+            if (!scalar) {
+                const unsigned long long cand = __ballot(valid && DG_H_INLEN(h) == 1);
+                unsigned long long M = 0;
+                int b = 256;
+                if (__popcll(cand) >= 2) b = dg_pick_group(cand, DG_H_BASE(h), last_out, lane, &M);
+                if (b != 256) {
+                    if (dgw_merge_out_group(g, u, nu, M, d, cnt, h, valid, lane, s_vic)) {
+                        merged = true;
+                        last_out = b;
+                        continue;                         // re-read u's list, look for the next group
+                    }
+                    if (lane == 0) dgg_merge_out(g, u);   // a list longer than a wave: literal path
+                    __syncthreads();
+                    g.err = __any((int)g.err);
+                    scalar = true;
+                    continue;
+                }
+            }
+            // AlnGraphBoost.cpp:143-158: mark out-edges visited, enqueue targets whose
+            // in-edges are now all visited, in out-list order
+            const int pend = DG_H_PEND(h) - 1;
+            if (valid) g.nd[d].pending = pend;
+            const unsigned long long rm = __ballot(valid && pend == 0);
+            if (valid && pend == 0) {
+                const uint32_t pos = qt + (uint32_t)__popcll(rm & DG_LT(lane));
+                if (pos < N) g.queue[pos] = d;
+            }
+            qt += (uint32_t)__popcll(rm);
+            if (qt > N) { if (lane == 0) dgg_fail(g, DG_E_INTERNAL); g.err = true; }
+            done = true;
+        }
+        if (!done && !g.err) {
+            // out list longer than a wave
             uint32_t nqt = qt;
             if (lane == 0) {
-                dgg_merge_in(g, u);
-                dgg_merge_out(g, u);
+                if (!scalar) dgg_merge_out(g, u);
                 const uint32_t off = g.nd[u].out_off;
                 const int len = g.nd[u].out_len;
                 for (int i = 0; i < len && !g.err; i++) {
@@ -386,9 +760,16 @@ __global__ __launch_bounds__(64) void k_merge(DgParams p) {
                     }
                 }
             }
-            __syncthreads();                             // lane 0's stores before anybody's loads
+            __syncthreads();
             qt = (uint32_t)__shfl((int)nqt, 0);
-            failed = __shfl((int)g.err, 0);
+            g.err = __any((int)g.err);
         }
+        failed = g.err;
+#ifdef DG_STAMPS
+        { unsigned long long now = clock64(); if (merged || scalar) { c_slow += now - t_prev; n_slow++; n_scalar += scalar; } else { c_fast += now - t_prev; n_fast++; } t_prev = now; }
+#endif
     }
+#ifdef DG_STAMPS
+    if (t == 0 && lane == 0) { p.st->dbg[0] = n_fast; p.st->dbg[1] = n_slow; p.st->dbg[2] = c_fast; p.st->dbg[3] = c_slow; p.st->dbg[4] = n_scalar; }
+#endif
 }
