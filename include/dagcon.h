@@ -188,7 +188,7 @@ typedef struct dagcon_graph_dump {
 } dagcon_graph_dump;
 int dagcon_debug_graph(dagcon_ctx *ctx, uint32_t target, dagcon_graph_dump *out);
 
-/* Diagnostic builds (-DDG_STAMPS) only: eight raw device counters of the last
+/* Diagnostic builds (-DDG_STAMPS) only: sixteen raw device counters of the last
  * run (in-kernel cycle stamps of target 0); all zero in the shipped build. */
 int dagcon_debug_counters(dagcon_ctx *ctx, unsigned long long *out8);
 

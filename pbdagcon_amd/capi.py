@@ -269,7 +269,7 @@ class Context:
         return res
 
     def debug_counters(self):
-        a = (C.c_ulonglong * 8)()
+        a = (C.c_ulonglong * 16)()
         self.L.dagcon_debug_counters.argtypes = [C.c_void_p, C.c_void_p]
         self._chk(self.L.dagcon_debug_counters(self.h, a))
         return list(a)

@@ -213,11 +213,11 @@ int launch_all(Ctx *c) {
     }
     HIPCHK(c, hipEventRecord(c->ev[2], s));
     if (c->T > 0 && !(c->opts.flags & DAGCON_FLAG_STOP_AFTER_BUILD))
-        hipLaunchKernelGGL(k_merge, dim3(c->T), dim3(64), 0, s, p);
+        hipLaunchKernelGGL(k_merge, dim3(c->T), dim3(128), 0, s, p);
     HIPCHK(c, hipEventRecord(c->ev[3], s));
     if (c->T > 0 && !(c->opts.flags & (DAGCON_FLAG_STOP_AFTER_BUILD | DAGCON_FLAG_STOP_AFTER_MERGE))) {
         hipLaunchKernelGGL(k_bp_prepare, dim3(c->T, 16), dim3(256), 0, s, p);
-        hipLaunchKernelGGL(k_bestpath, dim3(c->T), dim3(64), 0, s, p);
+        hipLaunchKernelGGL(k_bestpath, dim3(c->T), dim3(128), 0, s, p);
     }
     HIPCHK(c, hipEventRecord(c->ev[4], s));
     HIPCHK(c, hipGetLastError());
@@ -521,7 +521,7 @@ int dagcon_debug_counters(dagcon_ctx *ctx, unsigned long long *out8) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     DgStatus st;
     HIPCHK(c, hipMemcpy(&st, c->d_st.p, sizeof st, hipMemcpyDeviceToHost));
-    for (int i = 0; i < 8; i++) out8[i] = st.dbg[i];
+    for (int i = 0; i < 16; i++) out8[i] = st.dbg[i];
     return DAGCON_OK;
 }
 

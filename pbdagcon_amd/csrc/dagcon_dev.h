@@ -46,7 +46,7 @@ struct DgStatus {
     unsigned long long cns_top;    // bump cursor into the consensus blob
     unsigned long long seg_top;    // bump cursor into the segment arrays
     unsigned long long n_columns;  // normalised, trimmed columns
-    unsigned long long dbg[8];     // diagnostic build only (DG_STAMPS): cycle / visit counters of target 0
+    unsigned long long dbg[16];     // diagnostic build only (DG_STAMPS): cycle / visit counters of target 0
 };
 
 // One 32-byte record per vertex.  The first 16 bytes are what a neighbour needs to know

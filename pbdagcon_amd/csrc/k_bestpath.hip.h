@@ -48,11 +48,19 @@ __global__ __launch_bounds__(256) void k_bp_prepare(DgParams p) {
     }
 }
 
-__global__ __launch_bounds__(64) void k_bestpath(DgParams p) {
+__global__ __launch_bounds__(128) void k_bestpath(DgParams p) {
     const uint32_t t = blockIdx.x;
     if (dg_failed(p) || !p.tactive[t]) return;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const uint64_t nb = p.node_base[t];
+    __shared__ int s_prog;
+    __shared__ uint32_t s_len, s_nseg;
+    if (threadIdx.x == 0) s_prog = (int)p.n_nodes[t] - 1;
+    __syncthreads();
+    if (threadIdx.x >= 64) {                             // wave 1: prefetcher, exit -> enter
+        dg_prefetch_wave(p.nodes + nb, p.pool + p.pool_base[t], p.pool_size[t], (int)p.n_nodes[t], &s_prog, lane, -1);
+        return;
+    }
     DgNode *nd = p.nodes + nb;
     int32_t *best = p.best + nb;
     int32_t *queue = p.queue + nb;
@@ -62,11 +70,13 @@ __global__ __launch_bounds__(64) void k_bestpath(DgParams p) {
     const int exitv = (int)N - 1;
 
     if (lane == 0) queue[0] = exitv;
-    __syncthreads();
+    DG_WAVE_FENCE();
     uint32_t qh = 0, qt = 1;
     bool bad = false;
+    int prog = exitv;
     while (qh < qt) {
         const int n = queue[qh++];
+        if (n < prog) { prog = n; if (lane == 0) *(volatile int *)&s_prog = n; }
         const DgNode nn = nd[n];
         const int out_len = nn.out_len, in_len = nn.in_len;
         if (out_len <= 32 && in_len <= 32) {
@@ -90,15 +100,16 @@ __global__ __launch_bounds__(64) void k_bestpath(DgParams p) {
                     nd[nbr].pending = pend;
                 }
             }
-            // first maximum in list order: wave max, then the lowest lane that holds it
-            float mx = ns;
-            for (int o = 16; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-            mx = __shfl(mx, 0);                              // lanes 0-31 agree; take their value
-            const unsigned long long hit = __ballot(valid && is_out && ns == mx);
+            // :399-416 first maximum in list order: the out entries sit on lanes 0..out_len-1 in
+            // list order, so a scalar walk over them with strict '>' is the reference loop
             if (out_len > 0) {
-                const int bl = __ffsll((long long)hit) - 1;
-                const int bd = __shfl(nbr, bl);
-                if (lane == 0) { score[n].x = mx; best[n] = bd; }
+                float mx = -FLT_MAX;
+                int bd = -1;
+                for (int i = 0; i < out_len; i++) {
+                    const float x = __int_as_float(DG_RL(__float_as_int(ns), i));
+                    if (x > mx) { mx = x; bd = DG_RL(nbr, i); }
+                }
+                if (lane == 0 && bd >= 0) { score[n].x = mx; best[n] = bd; }
             }
             const unsigned long long rm = __ballot(valid && !is_out && pend == 0);
             if (valid && !is_out && pend == 0) {
@@ -127,16 +138,16 @@ __global__ __launch_bounds__(64) void k_bestpath(DgParams p) {
                     if (pend == 0 && nqt < N) queue[nqt++] = s;
                 }
             }
-            __syncthreads();
-            qt = (uint32_t)__shfl((int)nqt, 0);
+            DG_WAVE_FENCE();
+            qt = (uint32_t)DG_RL(nqt, 0);
         }
         if (qt > N) { bad = true; break; }
     }
+    if (lane == 0) *(volatile int *)&s_prog = DG_PROG_DONE;
     if (bad) { if (lane == 0) dg_fail(p, DG_E_INTERNAL); return; }
 
     // :443-456 walk the best edges from enter; :327-373 segmentation.  The walk
     // is a pointer chase; lane 0 does it and keeps the consensus in cns_tmp.
-    __shared__ uint32_t s_len, s_nseg;
     uint8_t *tmp = p.cns_tmp + nb;
     int32_t *segs = p.stk + (uint64_t)t * p.stk_words;      // (range0, range1) pairs
     if (lane == 0) {
@@ -184,7 +195,7 @@ __global__ __launch_bounds__(64) void k_bestpath(DgParams p) {
         p.seg_first[t] = so; p.n_seg[t] = nseg;
         s_len = keep; s_nseg = nseg;
     }
-    __syncthreads();
+    DG_WAVE_FENCE();
     const uint32_t keep = s_len, nseg = s_nseg;
     uint8_t *out = p.cns + p.cns_off[t];
     for (uint32_t i = lane; i < keep; i += 64) out[i] = tmp[i];

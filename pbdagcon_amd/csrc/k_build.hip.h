@@ -451,7 +451,7 @@ __device__ __forceinline__ uint32_t dg_pool_alloc(const DgParams &p, uint32_t t,
         off = atomicAdd(&p.pool_top[t], words);
         if ((uint64_t)off + words > p.pool_size[t]) { dg_fail(p, DG_E_POOL_TGT); p.st->bad_target = t; off = 0xFFFFFFFFu; }
     }
-    return __shfl(off, 0);
+    return (uint32_t)__builtin_amdgcn_readlane((int)off, 0);
 }
 
 __global__ __launch_bounds__(256) void k_lists(DgParams p) {
@@ -499,14 +499,14 @@ __global__ __launch_bounds__(256) void k_lists(DgParams p) {
                 if (pos <= blen) {
                     n_cov += (uint32_t)__popcll(covered);
                     n_match += (uint32_t)__popcll(__ballot(cell != 0u && idf != DG_CELL_DEL));
-                    if (covered) last_base = DG_CELL_BASE(__shfl(cell, 63 - __clzll((long long)covered)));
+                    if (covered) last_base = DG_CELL_BASE((uint32_t)__builtin_amdgcn_readlane((int)cell, 63 - __clzll((long long)covered)));
                 }
                 val = (cell != 0u && idf != DG_CELL_DEL) ? (int32_t)idf : 0;
             }
             unsigned long long rem = __ballot(val != 0);
             while (rem) {
                 const int first = __ffsll((long long)rem) - 1;
-                const int32_t x = __shfl(val, first);
+                const int32_t x = __builtin_amdgcn_readlane(val, first);
                 const unsigned long long same = __ballot(val == x);
                 rem &= ~same;
                 const int c = __popcll(same);

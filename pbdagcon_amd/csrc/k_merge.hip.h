@@ -310,10 +310,51 @@ __device__ inline void dgg_merge_out(DgGraph &g, int n) {
 }
 
 // ============================================================================
+// Prefetch wave.  The sweeps of stages (b) and (c) are dependent pointer chases:
+// what they cost is the latency of each access, and a first touch of a cache
+// line is an HBM miss.  Vertex ids are in backbone-position order, so the sweep
+// moves through the vertex records and their lists monotonically; a second
+// wave of the same workgroup (same CU, same L1) runs ahead of the worker and
+// touches the records and list heads it is about to need.  It only loads; it
+// never changes what the worker computes.
+// ============================================================================
+#define DG_PROG_DONE 0x7fffffff
+#define DG_PF_AHEAD 256
+#define DG_PF_CHUNK 64
+
+__device__ inline void dg_prefetch_wave(const DgNode *nd, const uint32_t *pool, uint32_t pool_size,
+                                        int N, volatile int *s_prog, int lane, int dir) {
+    int next = dir > 0 ? 0 : N - 1;
+    unsigned spins = 0;
+    uint32_t sink = 0;
+    for (;;) {
+        const int cur = *s_prog;
+        if (cur == DG_PROG_DONE) break;
+        const bool work = dir > 0 ? (next < N && next < cur + DG_PF_AHEAD) : (next >= 0 && next > cur - DG_PF_AHEAD);
+        if (!work) {
+            if ((dir > 0 ? next >= N : next < 0) || ++spins > 400000000u) break;
+            __builtin_amdgcn_s_sleep(4);
+            continue;
+        }
+        const int v = next + dir * lane;
+        if (v >= 0 && v < N) {
+            const uint4 h2 = *(reinterpret_cast<const uint4 *>(&nd[v]) + 1);
+            if (h2.x < pool_size) sink ^= pool[h2.x];
+            if (h2.y < pool_size) sink ^= pool[h2.y];
+        }
+        next += dir * DG_PF_CHUNK;
+    }
+    asm volatile("" ::"v"(sink));
+}
+
+// ============================================================================
 // Wave-cooperative merge.  Everything below is executed by all 64 lanes with
 // wave-uniform control flow; a lane holds one list entry.
 // ============================================================================
 #define DG_LT(lane) ((1ull << (lane)) - 1ull)
+// orders this wave's earlier stores (a single lane's, on the literal path) before its
+// later loads; the worker is one wave, so no s_barrier is involved
+#define DG_WAVE_FENCE() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup")
 
 __device__ __forceinline__ uint4 dg_lo16(const DgNode *n) { return *reinterpret_cast<const uint4 *>(n); }
 __device__ __forceinline__ uint4 dg_hi16(const DgNode *n) { return *(reinterpret_cast<const uint4 *>(n) + 1); }
@@ -328,6 +369,10 @@ __device__ __forceinline__ uint4 dg_hi16(const DgNode *n) { return *(reinterpret
 #define DG_H2_OUTCAP(h) ((int)((h).z & 0xffffu))
 #define DG_H2_INCAP(h)  ((int)((h).z >> 16))
 
+// v_readlane: the source lane is wave-uniform everywhere it is used here (it comes from a
+// ballot), so no cross-lane permute through the LDS crossbar is needed
+#define DG_RL(v, l) __builtin_amdgcn_readlane((int)(v), (int)(l))
+
 __device__ __forceinline__ int dg_wave_incl_scan(int v, int lane) {
     for (int o = 1; o < 64; o <<= 1) {
         const int up = __shfl_up(v, o);
@@ -339,7 +384,7 @@ __device__ __forceinline__ int dg_wave_sum_masked(int v, unsigned long long m) {
     int acc = 0;
     while (m) {
         const int f = __ffsll((long long)m) - 1;
-        acc += __shfl(v, f);
+        acc += DG_RL(v, f);
         m &= m - 1ull;
     }
     return acc;
@@ -353,7 +398,7 @@ __device__ __forceinline__ int dg_pick_group(unsigned long long cand, int base, 
     unsigned long long bm = 0;
     while (cand) {
         const int f = __ffsll((long long)cand) - 1;
-        const int b = __shfl(base, f);
+        const int b = DG_RL(base, f);
         const unsigned long long same = __ballot(((cand >> lane) & 1ull) && base == b);
         if (b > last && b < best && __popcll(same) >= 2) { best = b; bm = same; }
         cand &= ~same;
@@ -365,7 +410,7 @@ __device__ __forceinline__ int dg_pick_group(unsigned long long cand, int base, 
 __device__ __forceinline__ uint32_t dg_wave_alloc(DgGraph &g, uint32_t words, int lane) {
     uint32_t off = 0;
     if (lane == 0) off = dgg_alloc(g, words);
-    off = (uint32_t)__shfl((int)off, 0);
+    off = (uint32_t)DG_RL(off, 0);
     if (off == 0xFFFFFFFFu) g.err = true;                // every lane: keeps control flow uniform
     return off;
 }
@@ -408,33 +453,31 @@ __device__ inline void dgw_in_rewrite(DgGraph &g, int v, const volatile int *vic
 // target's record).  M = lanes of the group (survivor = lowest lane).
 // Returns false, with nothing modified, when a list involved is longer than a wave.
 __device__ inline bool dgw_merge_out_group(DgGraph &g, int u, const DgNode &nu, unsigned long long M,
-                                           int d, int cnt, uint4 h, bool valid_out, int lane,
+                                           int d, int &cnt, uint4 h, bool valid_out, int lane,
                                            volatile int *s_vic) {
     const int an_lane = __ffsll((long long)M) - 1;
     const unsigned long long vm = M & ~(1ull << an_lane);
-    const int an = __shfl(d, an_lane);
+    const int an = DG_RL(d, an_lane);
     const int k = __popcll(vm);
     const bool member = (M >> lane) & 1ull;
     uint4 h2 = make_uint4(0, 0, 0, 0);
     if (member) h2 = dg_hi16(&g.nd[d]);
     // members' out entries flattened onto lanes 0..L-1: survivor's first, then victims in order
-    const int my_len = member ? DG_H_OUTLEN(h) : 0;
-    const int incl = dg_wave_incl_scan(my_len, lane);
-    const int L = __shfl(incl, 63);
-    if (L > 64) return false;
-    const int my_start = incl - my_len;
-    int src = -1, e = 0;
+    int L = 0, src = -1, e = 0;
+    uint32_t src_off = 0;
     {
         unsigned long long mm = M;
         while (mm) {
             const int ml = __ffsll((long long)mm) - 1;
             mm &= mm - 1ull;
-            const int ms = __shfl(my_start, ml), mlen = __shfl(my_len, ml);
-            if (lane >= ms && lane < ms + mlen) { src = ml; e = lane - ms; }
+            const int mlen = DG_RL(DG_H_OUTLEN(h), ml);
+            const uint32_t moff = (uint32_t)DG_RL(DG_H2_OUTOFF(h2), ml);
+            if (lane >= L && lane < L + mlen) { src = ml; e = lane - L; src_off = moff; }
+            L += mlen;
         }
     }
+    if (L > 64) return false;
     const bool fl = lane < L;
-    const uint32_t src_off = (uint32_t)__shfl((int)DG_H2_OUTOFF(h2), src < 0 ? 0 : src);
     int n2 = -1, c2 = 0;
     if (fl) { n2 = (int)g.pool[src_off + 2 * e]; c2 = (int)g.pool[src_off + 2 * e + 1]; }
     const bool vic_entry = fl && src != an_lane;
@@ -452,7 +495,7 @@ __device__ inline bool dgw_merge_out_group(DgGraph &g, int u, const DgNode &nu, 
     int newcnt = c2;
     while (rem) {
         const int f = __ffsll((long long)rem) - 1;
-        const int x = __shfl(n2, f);
+        const int x = DG_RL(n2, f);
         const unsigned long long same = __ballot(fl && n2 == x);
         rem &= ~same;
         first_m |= 1ull << f;
@@ -469,8 +512,8 @@ __device__ inline bool dgw_merge_out_group(DgGraph &g, int u, const DgNode &nu, 
     // survivor's new out list
     {
         const int nlen = __popcll(first_m);
-        uint32_t off = (uint32_t)__shfl((int)DG_H2_OUTOFF(h2), an_lane);
-        int cap = __shfl(DG_H2_OUTCAP(h2), an_lane);
+        uint32_t off = (uint32_t)DG_RL(DG_H2_OUTOFF(h2), an_lane);
+        int cap = DG_RL(DG_H2_OUTCAP(h2), an_lane);
         if (nlen > cap) {
             uint32_t ncap = 2u * (uint32_t)(nlen + 1);
             if (ncap < 4) ncap = 4;
@@ -483,7 +526,7 @@ __device__ inline bool dgw_merge_out_group(DgGraph &g, int u, const DgNode &nu, 
             g.pool[off + 2 * idx] = (uint32_t)n2;
             g.pool[off + 2 * idx + 1] = (uint32_t)newcnt;
         }
-        const int an_w = __shfl(DG_H_WEIGHT(h), an_lane);   // all lanes: a shuffle under a divergent branch reads 0
+        const int an_w = DG_RL(DG_H_WEIGHT(h), an_lane);
         if (lane == 0) {
             DgNode *a = &g.nd[an];
             a->out_len = (uint16_t)nlen; a->out_off = off; a->out_cap = (uint16_t)cap;
@@ -497,7 +540,8 @@ __device__ inline bool dgw_merge_out_group(DgGraph &g, int u, const DgNode &nu, 
         if (keep) {
             const int idx = __popcll(km & DG_LT(lane));
             g.pool[nu.out_off + 2 * idx] = (uint32_t)d;
-            g.pool[nu.out_off + 2 * idx + 1] = (uint32_t)(lane == an_lane ? cnt + add_cnt : cnt);
+            if (lane == an_lane) cnt += add_cnt;
+            g.pool[nu.out_off + 2 * idx + 1] = (uint32_t)cnt;
         }
         if (lane == 0) g.nd[u].out_len = (uint16_t)__popcll(km);
     }
@@ -518,7 +562,7 @@ __device__ inline bool dgw_merge_in_group(DgGraph &g, int n, const DgNode &nn, u
                                           volatile int *s_vic, int *an_out) {
     const int an_lane = __ffsll((long long)M) - 1;
     const unsigned long long vm = M & ~(1ull << an_lane);
-    const int an = __shfl(s, an_lane);
+    const int an = DG_RL(s, an_lane);
     *an_out = an;
     const int k = __popcll(vm);
     const bool member = (M >> lane) & 1ull;
@@ -528,23 +572,21 @@ __device__ inline bool dgw_merge_in_group(DgGraph &g, int n, const DgNode &nn, u
     int c0 = 0;
     if (member) c0 = (int)g.pool[DG_H2_OUTOFF(h2) + 1];     // count of its single out edge (-> n)
     // victims' in entries flattened onto lanes 0..L-1, victims in order
-    const int my_len = victim ? DG_H_INLEN(h) : 0;
-    const int incl = dg_wave_incl_scan(my_len, lane);
-    const int L = __shfl(incl, 63);
-    if (L > 64) return false;
-    const int my_start = incl - my_len;
-    int src = -1, e = 0;
+    int L = 0, e = 0;
+    uint32_t src_off = 0;
     {
         unsigned long long mm = vm;
         while (mm) {
             const int ml = __ffsll((long long)mm) - 1;
             mm &= mm - 1ull;
-            const int ms = __shfl(my_start, ml), mlen = __shfl(my_len, ml);
-            if (lane >= ms && lane < ms + mlen) { src = ml; e = lane - ms; }
+            const int mlen = DG_RL(DG_H_INLEN(h), ml);
+            const uint32_t moff = (uint32_t)DG_RL(DG_H2_INOFF(h2), ml);
+            if (lane >= L && lane < L + mlen) { e = lane - L; src_off = moff; }
+            L += mlen;
         }
     }
+    if (L > 64) return false;
     const bool fl = lane < L;
-    const uint32_t src_off = (uint32_t)__shfl((int)DG_H2_INOFF(h2), src < 0 ? 0 : src);
     int n1 = -1;
     if (fl) n1 = (int)g.pool[src_off + e];
     uint4 hn1 = make_uint4(0, 0, 0, 0);
@@ -561,18 +603,18 @@ __device__ inline bool dgw_merge_in_group(DgGraph &g, int n, const DgNode &nn, u
         g.nd[an].weight = DG_H_WEIGHT(h) + add_w;
     }
     // :193-212 re-point the victims' in edges to the survivor, in order
-    uint32_t a_in_off = (uint32_t)__shfl((int)DG_H2_INOFF(h2), an_lane);
-    int a_in_cap = __shfl(DG_H2_INCAP(h2), an_lane);
-    int a_in_len = __shfl(DG_H_INLEN(h), an_lane);
+    uint32_t a_in_off = (uint32_t)DG_RL(DG_H2_INOFF(h2), an_lane);
+    int a_in_cap = DG_RL(DG_H2_INCAP(h2), an_lane);
+    int a_in_len = DG_RL(DG_H_INLEN(h), an_lane);
     bool a_dirty = false;
     unsigned long long rem = __ballot(fl);
     while (rem) {
         const int f = __ffsll((long long)rem) - 1;
-        const int x = __shfl(n1, f);
+        const int x = DG_RL(n1, f);
         rem &= ~__ballot(fl && n1 == x);
         // out[x]: drop the entries that point at victims, fold their counts into x->an
         const uint4 hx2 = dg_hi16(&g.nd[x]);
-        const int xlen = __shfl(DG_H_OUTLEN(hn1), f);
+        const int xlen = DG_RL(DG_H_OUTLEN(hn1), f);
         const uint32_t xoff = DG_H2_OUTOFF(hx2);
         int dst = -1, c = 0;
         if (lane < xlen) { dst = (int)g.pool[xoff + 2 * lane]; c = (int)g.pool[xoff + 2 * lane + 1]; }
@@ -629,12 +671,20 @@ __device__ inline bool dgw_merge_in_group(DgGraph &g, int n, const DgNode &nn, u
 
 // ---- mergeNodes (AlnGraphBoost.cpp:129-160): one wave per target ------------
 #define DG_IN_STACK 48
+#define DG_QRING 256
 
-__global__ __launch_bounds__(64) void k_merge(DgParams p) {
+__global__ __launch_bounds__(128) void k_merge(DgParams p) {
     const uint32_t t = blockIdx.x;
     if (dg_failed(p) || !p.tactive[t]) return;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const uint64_t nb = p.node_base[t];
+    __shared__ int s_prog;
+    if (threadIdx.x == 0) s_prog = 0;
+    __syncthreads();
+    if (threadIdx.x >= 64) {                             // wave 1: prefetcher
+        dg_prefetch_wave(p.nodes + nb, p.pool + p.pool_base[t], p.pool_size[t], (int)p.n_nodes[t], &s_prog, lane, +1);
+        return;
+    }
     DgGraph g;
     g.nd = p.nodes + nb; g.queue = p.queue + nb;
     g.pool = p.pool + p.pool_base[t]; g.pool_size = p.pool_size[t]; g.pool_top = p.pool_top + t;
@@ -643,17 +693,99 @@ __global__ __launch_bounds__(64) void k_merge(DgParams p) {
     const uint32_t N = p.n_nodes[t];
     __shared__ int s_vic[64];
     __shared__ int s_stk[2 * DG_IN_STACK];
+    __shared__ int s_ring[DG_QRING];                     // the youngest DG_QRING queue entries
     uint32_t qh = 0, qt = 1;
-    if (lane == 0) g.queue[0] = 0;                       // enter vertex
-    __syncthreads();
+    if (lane == 0) { g.queue[0] = 0; s_ring[0] = 0; }    // enter vertex
+    DG_WAVE_FENCE();
     int failed = 0;
+    int prog = 0;
 #ifdef DG_STAMPS
-    unsigned long long c_fast = 0, c_slow = 0, n_fast = 0, n_slow = 0, n_scalar = 0, t_prev = clock64();
+    unsigned long long c_fast = 0, c_slow = 0, n_fast = 0, n_slow = 0, n_scalar = 0, t_prev = clock64(), c_a = 0, c_b = 0, c_c = 0, c_grp = 0, ng_in = 0, ng_out = 0, c_odd = 0, n_odd = 0;
 #endif
     while (qh < qt && !failed) {
-        const int u = g.queue[qh++];
+        // an entry still in the LDS ring has not been overwritten: pushes so far are < qt <= qh + DG_QRING
+        const int u = (qt - qh <= DG_QRING) ? s_ring[qh & (DG_QRING - 1)] : g.queue[qh];
+        qh++;
         bool scalar = false, merged = false;
+#ifdef DG_STAMPS
+        unsigned long long ts_pre = 0, ts_in = 0, acc_grp = 0, n_grp_in = 0, n_grp_out = 0;
+        const unsigned long long ts0 = clock64();
+#endif
+        if (u > prog) { prog = u; if (lane == 0) *(volatile int *)&s_prog = u; }
 
+        // ---------------- the common case in one look: no merge group on either side --------
+        {
+            const DgNode nu = g.nd[u];
+            if (nu.in_len <= 32 && nu.out_len <= 32) {
+                const bool is_in = lane < 32;
+                const int idx = lane & 31;
+                const bool valid = is_in ? idx < nu.in_len : idx < nu.out_len;
+                int nbr = 0, cnt = 0;
+                if (valid) {
+                    if (is_in) nbr = (int)g.pool[nu.in_off + idx];
+                    else { nbr = (int)g.pool[nu.out_off + 2 * idx]; cnt = (int)g.pool[nu.out_off + 2 * idx + 1]; }
+                }
+                uint4 h = make_uint4(0, 0, 0, 0);
+                if (valid) h = dg_lo16(&g.nd[nbr]);
+                const unsigned long long cand =
+                    __ballot(valid && (is_in ? DG_H_OUTLEN(h) == 1 : DG_H_INLEN(h) == 1));
+                const unsigned long long c_in = cand & 0xffffffffull;
+                unsigned long long M = 0;
+                bool in_work = false;
+                if (__popcll(c_in) >= 2) in_work = dg_pick_group(c_in, DG_H_BASE(h), -1, lane, &M) != 256;
+                if (!in_work) {
+                    // mergeOutNodes(u) on the resident out entries (lanes 32..63), group by group
+                    bool live = valid && !is_in;
+                    int last_out = -1;
+                    bool bail = false;
+                    for (;;) {
+                        const unsigned long long c_out = __ballot(live && DG_H_INLEN(h) == 1);
+                        int b = 256;
+                        if (__popcll(c_out) >= 2) b = dg_pick_group(c_out, DG_H_BASE(h), last_out, lane, &M);
+                        if (b == 256) break;
+#ifdef DG_STAMPS
+                        const unsigned long long tg0 = clock64();
+#endif
+                        const bool okg = dgw_merge_out_group(g, u, nu, M, nbr, cnt, h, live, lane, s_vic);
+#ifdef DG_STAMPS
+                        c_grp += clock64() - tg0; ng_out++;
+#endif
+                        if (!okg) { bail = true; break; }
+                        merged = true;
+                        if (g.err) break;
+                        last_out = b;
+                        const int an_lane = __ffsll((long long)M) - 1;
+                        if (((M >> lane) & 1ull) && lane != an_lane) live = false;     // victims are gone
+                        if (live) h = dg_lo16(&g.nd[nbr]);                             // pending / lens may have moved
+                    }
+                    if (!bail) {
+                        if (!g.err) {
+                            // AlnGraphBoost.cpp:143-158
+                            const int pend = DG_H_PEND(h) - 1;
+                            if (live) g.nd[nbr].pending = pend;
+                            const unsigned long long rm = __ballot(live && pend == 0);
+                            if (live && pend == 0) {
+                                const uint32_t pos = qt + (uint32_t)__popcll(rm & DG_LT(lane));
+                                if (pos < N) { g.queue[pos] = nbr; s_ring[pos & (DG_QRING - 1)] = nbr; }
+                            }
+                            qt += (uint32_t)__popcll(rm);
+                            if (qt > N) { if (lane == 0) dgg_fail(g, DG_E_INTERNAL); g.err = true; }
+                        }
+                        failed = g.err;
+#ifdef DG_STAMPS
+                        { unsigned long long now = clock64(); if (merged) { c_slow += now - t_prev; n_slow++; } else { c_fast += now - t_prev; n_fast++; } t_prev = now; }
+#endif
+                        continue;
+                    }
+                    // a list longer than a wave is involved: nothing was modified by the refused
+                    // group; the generic path below re-reads the vertex
+                }
+            }
+        }
+
+#ifdef DG_STAMPS
+        ts_pre = clock64();
+#endif
         // ---------------- mergeInNodes(u), recursion on an explicit stack ----------------
         int sp = 1;
         int fr_n = u, fr_last = -1;                       // top frame lives in registers
@@ -676,7 +808,13 @@ __global__ __launch_bounds__(64) void k_merge(DgParams p) {
             }
             if (sp >= DG_IN_STACK) { scalar = true; break; }
             int an = -1;
+#ifdef DG_STAMPS
+            const unsigned long long tg0 = clock64();
+#endif
             if (!dgw_merge_in_group(g, fr_n, nn, M, s, h, valid, lane, s_vic, &an)) { scalar = true; break; }
+#ifdef DG_STAMPS
+            acc_grp += clock64() - tg0; n_grp_in++;
+#endif
             merged = true;
             if (g.err) break;
             fr_last = b;
@@ -691,15 +829,18 @@ __global__ __launch_bounds__(64) void k_merge(DgParams p) {
                 dgg_merge_in(g, fr_n);
                 for (int f = sp - 2; f >= 0 && !g.err; f--) dgg_merge_in(g, s_stk[2 * f]);
             }
-            __syncthreads();
+            DG_WAVE_FENCE();
             g.err = __any((int)g.err);
         }
 
+#ifdef DG_STAMPS
+        ts_in = clock64();
+#endif
         // ---------------- mergeOutNodes(u) + FIFO bookkeeping ----------------
         bool done = false;
         if (scalar) {
             if (lane == 0 && !g.err) dgg_merge_out(g, u);
-            __syncthreads();
+            DG_WAVE_FENCE();
             g.err = __any((int)g.err);
         }
         int last_out = -1;
@@ -718,13 +859,20 @@ __global__ __launch_bounds__(64) void k_merge(DgParams p) {
                 int b = 256;
                 if (__popcll(cand) >= 2) b = dg_pick_group(cand, DG_H_BASE(h), last_out, lane, &M);
                 if (b != 256) {
+#ifdef DG_STAMPS
+                    const unsigned long long tg0 = clock64();
+                    const bool okg = dgw_merge_out_group(g, u, nu, M, d, cnt, h, valid, lane, s_vic);
+                    acc_grp += clock64() - tg0; n_grp_out++;
+                    if (okg) {
+#else
                     if (dgw_merge_out_group(g, u, nu, M, d, cnt, h, valid, lane, s_vic)) {
+#endif
                         merged = true;
                         last_out = b;
                         continue;                         // re-read u's list, look for the next group
                     }
                     if (lane == 0) dgg_merge_out(g, u);   // a list longer than a wave: literal path
-                    __syncthreads();
+                    DG_WAVE_FENCE();
                     g.err = __any((int)g.err);
                     scalar = true;
                     continue;
@@ -737,7 +885,7 @@ __global__ __launch_bounds__(64) void k_merge(DgParams p) {
             const unsigned long long rm = __ballot(valid && pend == 0);
             if (valid && pend == 0) {
                 const uint32_t pos = qt + (uint32_t)__popcll(rm & DG_LT(lane));
-                if (pos < N) g.queue[pos] = d;
+                if (pos < N) { g.queue[pos] = d; s_ring[pos & (DG_QRING - 1)] = d; }
             }
             qt += (uint32_t)__popcll(rm);
             if (qt > N) { if (lane == 0) dgg_fail(g, DG_E_INTERNAL); g.err = true; }
@@ -756,20 +904,22 @@ __global__ __launch_bounds__(64) void k_merge(DgParams p) {
                     g.nd[v].pending = pend;
                     if (pend == 0) {
                         if (nqt >= N) { dgg_fail(g, DG_E_INTERNAL); break; }
+                        s_ring[nqt & (DG_QRING - 1)] = v;
                         g.queue[nqt++] = v;
                     }
                 }
             }
-            __syncthreads();
-            qt = (uint32_t)__shfl((int)nqt, 0);
+            DG_WAVE_FENCE();
+            qt = (uint32_t)DG_RL(nqt, 0);
             g.err = __any((int)g.err);
         }
         failed = g.err;
 #ifdef DG_STAMPS
-        { unsigned long long now = clock64(); if (merged || scalar) { c_slow += now - t_prev; n_slow++; n_scalar += scalar; } else { c_fast += now - t_prev; n_fast++; } t_prev = now; }
+        { unsigned long long now = clock64(); if (merged || scalar) { c_slow += now - t_prev; n_slow++; n_scalar += scalar; c_a += ts_pre - ts0; c_b += ts_in - ts_pre; c_c += now - ts_in; c_grp += acc_grp; ng_in += n_grp_in; ng_out += n_grp_out; } else { c_fast += now - t_prev; n_fast++; c_odd += now - t_prev; n_odd++; } t_prev = now; }
 #endif
     }
+    if (lane == 0) *(volatile int *)&s_prog = DG_PROG_DONE;
 #ifdef DG_STAMPS
-    if (t == 0 && lane == 0) { p.st->dbg[0] = n_fast; p.st->dbg[1] = n_slow; p.st->dbg[2] = c_fast; p.st->dbg[3] = c_slow; p.st->dbg[4] = n_scalar; }
+    if (t == 0 && lane == 0) { p.st->dbg[0] = n_fast; p.st->dbg[1] = n_slow; p.st->dbg[2] = c_fast; p.st->dbg[3] = c_slow; p.st->dbg[4] = n_scalar; p.st->dbg[5] = c_a; p.st->dbg[6] = c_b; p.st->dbg[7] = c_c; p.st->dbg[8] = c_grp; p.st->dbg[9] = ng_in; p.st->dbg[10] = ng_out; p.st->dbg[11] = c_odd; p.st->dbg[12] = n_odd; }
 #endif
 }
