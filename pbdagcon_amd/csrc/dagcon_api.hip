@@ -193,6 +193,7 @@ int launch_all(Ctx *c) {
     if (c->A > 0) {
         hipLaunchKernelGGL(k_count, dim3(c->A), dim3(256), 0, s, p);
         hipLaunchKernelGGL(k_normalize, dim3((c->A + 63) / 64), dim3(64), 0, s, p);
+        hipLaunchKernelGGL(k_normalize_slow, dim3((c->A + 63) / 64), dim3(64), 0, s, p);
     }
     HIPCHK(c, hipEventRecord(c->ev[1], s));
     if (c->mat_cells) {
@@ -574,6 +575,7 @@ static int normalize_impl(Ctx *c, dagcon_ctx *ctx, uint32_t n, const uint32_t *a
         if (c->A) {
             hipLaunchKernelGGL(k_count, dim3(c->A), dim3(256), 0, c->stream, p);
             hipLaunchKernelGGL(k_normalize, dim3((c->A + 63) / 64), dim3(64), 0, c->stream, p);
+            hipLaunchKernelGGL(k_normalize_slow, dim3((c->A + 63) / 64), dim3(64), 0, c->stream, p);
         }
         HIPCHK(c, hipGetLastError());
         if ((r = read_status(c))) return r;

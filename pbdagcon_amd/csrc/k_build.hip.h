@@ -66,12 +66,91 @@ __global__ __launch_bounds__(256) void k_count(DgParams p) {
 // k_normalize: one lane per alignment; sequential by nature (gap pushing is a
 // left-to-right rewrite with unbounded look-ahead), parallel over alignments.
 // Columns are uint16: low byte = query char, high byte = target char.
+//
+// The fast kernel streams: 16 input columns per 16-byte load, expanded into a
+// per-lane LDS window; the push loop (Alignment.cpp:165-198) runs on the window
+// with its two monotone look-ahead cursors and pauses when a look-ahead reaches
+// the end of the window (its steps are idempotent, see below); finished columns
+// leave as plain 2-byte stores.  An alignment whose look-ahead outgrows the
+// window (a gap run of ~100 columns) is flagged and redone by
+// k_normalize_slow, the same algorithm on HBM.
 // ---------------------------------------------------------------------------
 #define DG_COL(qb, tb) ((uint16_t)((uint16_t)(qb) | ((uint16_t)(tb) << 8)))
 #define DG_Q(c) ((uint8_t)((c) & 0xff))
 #define DG_T(c) ((uint8_t)((c) >> 8))
+#define DG_NW 128u            // LDS window: columns per lane (power of two)
+#define DG_NW_STRIDE 130u     // uint16 per lane row: 65 dwords, odd, so lanes spread over banks
+#define DG_REDO 0xFFFFFFFFu   // n_hi marker: redo on the slow path
+
+// trimAln, column counts, conformity, insertion runs: what follows normalizeGaps for
+// both kernels.  buf holds the m final columns.
+__device__ inline void dg_finish_alignment(const DgParams &p, uint32_t a, uint16_t *buf, uint32_t m) {
+    // Alignment.cpp:219-242 trimAln (a no-op for trim == 0)
+    const uint32_t trim = p.trim;
+    uint32_t lbases = 0, rbases = 0, lo = 0, hi = m;
+    uint32_t start = p.aln_start[a];
+    while (lbases < trim && lo < m) {
+        if (DG_T(buf[lo++]) != DG_GAP) lbases++;
+    }
+    while (rbases < trim && hi > lo) {
+        if (DG_T(buf[--hi]) != DG_GAP) rbases++;
+    }
+    start += lbases;
+    // what addAln will do with the window: insertions create vertices, matches and
+    // deletions advance the backbone cursor (AlnGraphBoost.cpp:75-104); the insertion run
+    // length per (position, read) numbers the inserted vertices
+    const bool graph = !(p.flags & DG_F_A1_ONLY);
+    uint32_t t_idx = 0, r = 0, K = 0;
+    uint32_t *Cm = nullptr;
+    if (graph) {
+        t_idx = p.aln_tgt[a];
+        if (p.tactive[t_idx]) {
+            const uint64_t ab = p.aln_begin[t_idx];
+            r = (uint32_t)(a - ab);
+            K = (uint32_t)(p.aln_begin[t_idx + 1] - ab);
+            Cm = p.matC + p.mat_base[t_idx];
+        }
+    }
+    const uint32_t tlen = graph ? p.tlen[t_idx] : 0xFFFFFFFFu;
+    uint32_t n_ins = 0, n_del = 0, adv = 0, run = 0;
+    bool conf = start >= 1;
+    uint32_t i = lo;
+    // 8 columns per 16-byte load once the index is a multiple of 8 (buffers are 16-byte aligned)
+#define DG_FIN_COL(c)                                                                     \
+    do {                                                                                  \
+        const uint8_t qb_ = DG_Q(c), tb_ = DG_T(c);                                       \
+        if (qb_ == tb_ || qb_ == DG_GAP) {                                                \
+            if (run) { if (Cm && conf && start + adv <= tlen + 1) Cm[(uint64_t)(start + adv) * K + r] = run; run = 0; } \
+            adv++; n_del += (qb_ != tb_);                                                 \
+            if ((uint64_t)start - 1 + adv > (uint64_t)tlen) conf = false;                 \
+        } else if (tb_ == DG_GAP) { n_ins++; run++; }                                     \
+    } while (0)
+    while (i < hi && (i & 7u)) { const uint16_t c = buf[i++]; DG_FIN_COL(c); }
+    while (i + 8 <= hi) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(buf + i);
+        const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint16_t c0 = (uint16_t)(w4[k] & 0xffffu), c1 = (uint16_t)(w4[k] >> 16);
+            DG_FIN_COL(c0);
+            DG_FIN_COL(c1);
+        }
+        i += 8;
+    }
+    while (i < hi) { const uint16_t c = buf[i++]; DG_FIN_COL(c); }
+    if (run && Cm && conf && start + adv <= tlen + 1) Cm[(uint64_t)(start + adv) * K + r] = run;
+#undef DG_FIN_COL
+    p.n_lo[a] = lo; p.n_hi[a] = hi; p.n_start[a] = start;
+    p.n_ins[a] = n_ins; p.n_del[a] = n_del;
+    atomicAdd(&p.st->n_columns, (unsigned long long)(hi - lo));
+    if (graph && hi > lo && !conf) {
+        dg_fail(p, DG_E_NONCONF);
+        p.st->bad_aln = a;
+    }
+}
 
 __global__ __launch_bounds__(64) void k_normalize(DgParams p) {
+    __shared__ uint16_t s_win[64 * DG_NW_STRIDE];
     const uint32_t a = blockIdx.x * 64 + threadIdx.x;
     if (a >= p.A) return;
     if (dg_failed(p)) return;
@@ -79,9 +158,102 @@ __global__ __launch_bounds__(64) void k_normalize(DgParams p) {
     const uint32_t len = p.aln_len[a];
     const uint8_t *q = p.q + off, *t = p.t + off;
     uint16_t *buf = p.norm + p.norm_off[a];
-    const bool raw = (p.flags & DG_F_RAW) != 0;
+    if (p.flags & DG_F_RAW) { p.n_hi[a] = DG_REDO; return; }   // raw columns: the slow kernel copies them
+    uint16_t *win = s_win + threadIdx.x * DG_NW_STRIDE;
+#define DG_W(x) win[(x) & (DG_NW - 1u)]
 
-    // Alignment.cpp:142-159: dots to dashes, mismatches to a deletion + an insertion
+    uint32_t ip = 0, e = 0, i = 0, w = 0, jt = 0, jq = 0;
+    bool in_done = (len == 0), overflow = false;
+    for (;;) {
+        // ---- refill: Alignment.cpp:142-159 on the next (up to) 16 input columns ----
+        if (!in_done) {
+            if ((e - i) + 32u > DG_NW) { overflow = true; break; }
+            uint32_t take = len - ip;
+            if (take > 16u) take = 16u;
+            unsigned long long q0 = 0, q1 = 0, t0 = 0, t1 = 0;
+            if (take == 16u && (((uintptr_t)(q + ip)) & 15u) == 0) {
+                const uint4 qv = *reinterpret_cast<const uint4 *>(q + ip);
+                const uint4 tv = *reinterpret_cast<const uint4 *>(t + ip);
+                q0 = (unsigned long long)qv.x | ((unsigned long long)qv.y << 32);
+                q1 = (unsigned long long)qv.z | ((unsigned long long)qv.w << 32);
+                t0 = (unsigned long long)tv.x | ((unsigned long long)tv.y << 32);
+                t1 = (unsigned long long)tv.z | ((unsigned long long)tv.w << 32);
+            } else {
+                // head (up to the next 16-byte boundary) and tail: byte loads
+                const uint32_t to_align = (uint32_t)((16u - (((uintptr_t)(q + ip)) & 15u)) & 15u);
+                if (to_align && take > to_align) take = to_align;
+                for (uint32_t k = 0; k < take; k++) {
+                    const unsigned long long qb = q[ip + k], tb = t[ip + k];
+                    if (k < 8) { q0 |= qb << (8 * k); t0 |= tb << (8 * k); }
+                    else { q1 |= qb << (8 * (k - 8)); t1 |= tb << (8 * (k - 8)); }
+                }
+            }
+            for (uint32_t k = 0; k < take; k++) {
+                uint8_t qb = (uint8_t)((k < 8 ? q0 >> (8 * k) : q1 >> (8 * (k - 8))) & 0xffu);
+                uint8_t tb = (uint8_t)((k < 8 ? t0 >> (8 * k) : t1 >> (8 * (k - 8))) & 0xffu);
+                if (qb == '.') qb = DG_GAP;
+                if (tb == '.') tb = DG_GAP;
+                if (qb != tb && qb != DG_GAP && tb != DG_GAP) {
+                    DG_W(e) = DG_COL(DG_GAP, tb); e++;
+                    DG_W(e) = DG_COL(qb, DG_GAP); e++;
+                } else {
+                    DG_W(e) = DG_COL(qb, tb); e++;
+                }
+            }
+            ip += take;
+            if (ip == len) in_done = true;
+        }
+        // ---- Alignment.cpp:165-198 push gaps to the right, as far as the window reaches.
+        // jt / jq only move forward (a column left of a cursor is never turned back into
+        // a base).  A step that runs out of window stores what it has done to column i
+        // and is restarted after the refill: the t-pass of a restarted step either finds
+        // its column already filled or repeats the same fruitless look-up. ----
+        while (i < e) {
+            if (i + 1 == e && !in_done) break;            // not known yet whether i is the last column
+            const uint16_t c = DG_W(i);
+            uint8_t qi = DG_Q(c), ti = DG_T(c);
+            bool more = false;
+            if (i + 1 < e) {
+                if (ti == DG_GAP) {
+                    if (jt <= i) jt = i + 1;
+                    while (jt < e && DG_T(DG_W(jt)) == DG_GAP) jt++;
+                    if (jt < e) {
+                        const uint16_t cj = DG_W(jt);
+                        if (DG_T(cj) == qi) { ti = qi; DG_W(jt) = DG_COL(DG_Q(cj), DG_GAP); }
+                    } else if (!in_done) more = true;
+                }
+                if (!more && qi == DG_GAP) {
+                    if (jq <= i) jq = i + 1;
+                    while (jq < e && DG_Q(DG_W(jq)) == DG_GAP) jq++;
+                    if (jq < e) {
+                        const uint16_t cj = DG_W(jq);
+                        if (DG_Q(cj) == ti) { qi = ti; DG_W(jq) = DG_COL(DG_GAP, DG_T(cj)); }
+                    } else if (!in_done) more = true;
+                }
+            }
+            if (more) { DG_W(i) = DG_COL(qi, ti); break; }
+            if (qi != DG_GAP || ti != DG_GAP) buf[w++] = DG_COL(qi, ti);   // :209-214
+            i++;
+        }
+        if (in_done && i == e) break;
+    }
+#undef DG_W
+    if (overflow) { p.n_hi[a] = DG_REDO; return; }
+    dg_finish_alignment(p, a, buf, w);
+}
+
+// The same algorithm with the whole expanded alignment in HBM: raw mode and
+// alignments whose look-ahead outgrew the LDS window.
+__global__ __launch_bounds__(64) void k_normalize_slow(DgParams p) {
+    const uint32_t a = blockIdx.x * 64 + threadIdx.x;
+    if (a >= p.A) return;
+    if (dg_failed(p)) return;
+    if (p.n_hi[a] != DG_REDO) return;
+    const uint64_t off = p.aln_off[a];
+    const uint32_t len = p.aln_len[a];
+    const uint8_t *q = p.q + off, *t = p.t + off;
+    uint16_t *buf = p.norm + p.norm_off[a];
+    const bool raw = (p.flags & DG_F_RAW) != 0;
     uint32_t n = 0;
     for (uint32_t i = 0; i < len; i++) {
         uint8_t qb = q[i], tb = t[i];
@@ -96,16 +268,8 @@ __global__ __launch_bounds__(64) void k_normalize(DgParams p) {
         }
         buf[n++] = DG_COL(qb, tb);
     }
-
-    uint32_t m = n;      // final column count
-    uint32_t lo = 0, hi = n;
-    uint32_t start = p.aln_start[a];
+    uint32_t m = n;
     if (!raw) {
-        // Alignment.cpp:165-198: push gaps to the right.  jt / jq are the
-        // look-ahead cursors of the two inner while loops; they only move
-        // forward (a column left of the cursor is never turned back into a
-        // base), so the whole pass is O(n).  Column i is final once the loop
-        // has passed it, so the all-gap filter of :209-214 is fused in.
         uint32_t w = 0, jt = 0, jq = 0;
         for (uint32_t i = 0; i < n; i++) {
             uint16_t c = buf[i];
@@ -116,10 +280,7 @@ __global__ __launch_bounds__(64) void k_normalize(DgParams p) {
                     while (jt < n && DG_T(buf[jt]) == DG_GAP) jt++;
                     if (jt < n) {
                         uint16_t cj = buf[jt];
-                        if (DG_T(cj) == qi) {
-                            ti = qi;
-                            buf[jt] = DG_COL(DG_Q(cj), DG_GAP);
-                        }
+                        if (DG_T(cj) == qi) { ti = qi; buf[jt] = DG_COL(DG_Q(cj), DG_GAP); }
                     }
                 }
                 if (qi == DG_GAP) {
@@ -127,10 +288,7 @@ __global__ __launch_bounds__(64) void k_normalize(DgParams p) {
                     while (jq < n && DG_Q(buf[jq]) == DG_GAP) jq++;
                     if (jq < n) {
                         uint16_t cj = buf[jq];
-                        if (DG_Q(cj) == ti) {
-                            qi = ti;
-                            buf[jq] = DG_COL(DG_GAP, DG_T(cj));
-                        }
+                        if (DG_Q(cj) == ti) { qi = ti; buf[jq] = DG_COL(DG_GAP, DG_T(cj)); }
                     }
                 }
             }
@@ -138,58 +296,7 @@ __global__ __launch_bounds__(64) void k_normalize(DgParams p) {
         }
         m = w;
     }
-    {
-        // Alignment.cpp:219-242 trimAln (a no-op for trim == 0)
-        const uint32_t trim = p.trim;
-        uint32_t lbases = 0, rbases = 0;
-        lo = 0; hi = m;
-        while (lbases < trim && lo < m) {
-            if (DG_T(buf[lo++]) != DG_GAP) lbases++;
-        }
-        while (rbases < trim && hi > lo) {
-            if (DG_T(buf[--hi]) != DG_GAP) rbases++;
-        }
-        start += lbases;
-    }
-
-    // what addAln will do with the window: insertions create vertices,
-    // matches and deletions advance the backbone cursor (AlnGraphBoost.cpp:75-104)
-    uint32_t n_ins = 0, n_del = 0, adv = 0;
-    for (uint32_t i = lo; i < hi; i++) {
-        uint16_t c = buf[i];
-        uint8_t qb = DG_Q(c), tb = DG_T(c);
-        if (qb == tb) adv++;
-        else if (qb == DG_GAP) { adv++; n_del++; }
-        else if (tb == DG_GAP) n_ins++;
-    }
-    p.n_lo[a] = lo; p.n_hi[a] = hi; p.n_start[a] = start;
-    p.n_ins[a] = n_ins; p.n_del[a] = n_del;
-    atomicAdd(&p.st->n_columns, (unsigned long long)(hi - lo));
-    if (p.flags & DG_F_A1_ONLY) return;
-    const uint32_t t_idx = p.aln_tgt[a];
-    const uint32_t tlen = p.tlen[t_idx];
-    if (hi > lo && (start < 1 || (uint64_t)start - 1 + adv > (uint64_t)tlen)) {
-        dg_fail(p, DG_E_NONCONF);
-        p.st->bad_aln = a;
-        return;
-    }
-    // insertion run length per (position, read): numbers the inserted vertices
-    if (n_ins && p.tactive[t_idx]) {
-        const uint64_t ab = p.aln_begin[t_idx];
-        const uint32_t r = (uint32_t)(a - ab);
-        const uint32_t K = (uint32_t)(p.aln_begin[t_idx + 1] - ab);
-        uint32_t *Cm = p.matC + p.mat_base[t_idx];
-        uint32_t bbpos = start, run = 0;
-        for (uint32_t i = lo; i < hi; i++) {
-            uint16_t c = buf[i];
-            uint8_t qb = DG_Q(c), tb = DG_T(c);
-            if (qb == tb || qb == DG_GAP) {
-                if (run) { Cm[(uint64_t)bbpos * K + r] = run; run = 0; }
-                bbpos++;
-            } else if (tb == DG_GAP) run++;
-        }
-        if (run) Cm[(uint64_t)bbpos * K + r] = run;
-    }
+    dg_finish_alignment(p, a, buf, m);
 }
 
 // ---------------------------------------------------------------------------
@@ -400,33 +507,58 @@ __global__ __launch_bounds__(64) void k_emit(DgParams p) {
         }                                                                    \
     } while (0)
 
-    for (uint32_t i = lo; i < hi; i++) {
-        const uint16_t c = buf[i];
-        const uint8_t qb = DG_Q(c), tb = DG_T(c);
-        if (qb == tb) {                                   // match  (AlnGraphBoost.cpp:75-85)
-            const uint32_t cur = bid[bbpos];
-            Am[(uint64_t)bbpos * K + r] = ((uint32_t)tb << 25) | (prev + 1u);
-            DG_DEPART(cur);
-            prev = cur; prev_pos = bbpos; prev_bb = true;
-            bbpos++;
-        } else if (qb == DG_GAP) {                        // deletion (:87-93)
-            Am[(uint64_t)bbpos * K + r] = ((uint32_t)tb << 25) | DG_CELL_DEL;
-            bbpos++;
-        } else if (tb == DG_GAP) {                        // insertion (:95-104)
-            if (ins_pos != bbpos) { ins_pos = bbpos; ins_id = gbase[bbpos] + Cm[(uint64_t)bbpos * K + r]; }
-            const uint32_t id = ins_id++;
-            const uint32_t rk = id - bbpos;               // bbpos backbone vertices precede group bbpos
-            DgNode nd;
-            nd.out_len = 1; nd.in_len = 1; nd.base = qb; nd.flags = 0; nd.pad = 0;
-            nd.weight = 1; nd.pending = 1;
-            nd.out_off = 3u * rk; nd.in_off = 3u * rk + 2u; nd.out_cap = 1; nd.in_cap = 1;
-            nd.bbpos = (int32_t)bbpos;
-            p.nodes[nb + id] = nd;
-            pool[3u * rk + 2u] = prev;
-            DG_DEPART(id);
-            prev = id; prev_pos = bbpos; prev_bb = false;
+    // backbone ids of 4 consecutive positions per 16-byte load (the cursor moves forward)
+    const uint32_t *bid_abs = p.bid;
+    uint64_t bid_q = ~0ull;
+    uint4 bid_v = make_uint4(0, 0, 0, 0);
+#define DG_EMIT_COL(c)                                                                             \
+    do {                                                                                           \
+        const uint8_t qb = DG_Q(c), tb = DG_T(c);                                                  \
+        if (qb == tb) { /* match (AlnGraphBoost.cpp:75-85) */                                      \
+            const uint64_t ax = bv + bbpos;                                                        \
+            if ((ax & ~3ull) != bid_q) { bid_q = ax & ~3ull; bid_v = *reinterpret_cast<const uint4 *>(bid_abs + bid_q); } \
+            const uint32_t k4 = (uint32_t)(ax & 3ull);                                             \
+            const uint32_t cur = k4 == 0 ? bid_v.x : k4 == 1 ? bid_v.y : k4 == 2 ? bid_v.z : bid_v.w; \
+            Am[(uint64_t)bbpos * K + r] = ((uint32_t)tb << 25) | (prev + 1u);                     \
+            DG_DEPART(cur);                                                                        \
+            prev = cur; prev_pos = bbpos; prev_bb = true;                                          \
+            bbpos++;                                                                               \
+        } else if (qb == DG_GAP) { /* deletion (:87-93) */                                         \
+            Am[(uint64_t)bbpos * K + r] = ((uint32_t)tb << 25) | DG_CELL_DEL;                      \
+            bbpos++;                                                                               \
+        } else if (tb == DG_GAP) { /* insertion (:95-104) */                                       \
+            if (ins_pos != bbpos) { ins_pos = bbpos; ins_id = gbase[bbpos] + Cm[(uint64_t)bbpos * K + r]; } \
+            const uint32_t id = ins_id++;                                                          \
+            const uint32_t rk = id - bbpos; /* bbpos backbone vertices precede group bbpos */      \
+            DgNode nd;                                                                             \
+            nd.out_len = 1; nd.in_len = 1; nd.base = qb; nd.flags = 0; nd.pad = 0;                 \
+            nd.weight = 1; nd.pending = 1;                                                         \
+            nd.out_off = 3u * rk; nd.in_off = 3u * rk + 2u; nd.out_cap = 1; nd.in_cap = 1;         \
+            nd.bbpos = (int32_t)bbpos;                                                             \
+            p.nodes[nb + id] = nd;                                                                 \
+            pool[3u * rk + 2u] = prev;                                                             \
+            DG_DEPART(id);                                                                         \
+            prev = id; prev_pos = bbpos; prev_bb = false;                                          \
+        }                                                                                          \
+    } while (0)
+
+    {
+        uint32_t i = lo;
+        while (i < hi && (i & 7u)) { const uint16_t c = buf[i++]; DG_EMIT_COL(c); }
+        while (i + 8 <= hi) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(buf + i);
+            const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint16_t c0 = (uint16_t)(w4[k] & 0xffffu), c1 = (uint16_t)(w4[k] >> 16);
+                DG_EMIT_COL(c0);
+                DG_EMIT_COL(c1);
+            }
+            i += 8;
         }
+        while (i < hi) { const uint16_t c = buf[i++]; DG_EMIT_COL(c); }
     }
+#undef DG_EMIT_COL
     Am[(uint64_t)exitpos * K + r] = prev + 1u;            // :106
     DG_DEPART(bid[exitpos]);
 #undef DG_DEPART

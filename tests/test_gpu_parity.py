@@ -254,6 +254,40 @@ def test_deep_coverage_more_than_one_wave(gpu_ctx_factory):
     _check_batch(gpu_ctx_factory, batch, min_cov=6, min_len=10, trim=2)
 
 
+def test_long_gap_runs_take_the_redo_path(gpu_ctx_factory):
+    """Gap runs longer than k_normalize's LDS window (an insertion or deletion of hundreds of
+    columns, homopolymers a gap slides through) are redone by k_normalize_slow; same answer."""
+    rng = np.random.default_rng(21)
+    tl = 900
+    alns, bb = random_target(rng, tl, 8, alphabet=b"ACGT", full_span=True, sub=0.02, ins=0.08, dele=0.04)
+    bbs = bytearray(bb)
+    bbs[300:520] = b"A" * 220                      # long homopolymer in the backbone
+    bb = bytes(bbs)
+    extra = []
+    for k in range(6):
+        q, t = bytearray(), bytearray()
+        for i in range(tl):
+            if k % 3 == 0 and i == 200:            # 300-column insertion
+                ins = bytes(b"ACGT"[j] for j in rng.integers(0, 4, 300))
+                q += ins; t += b"-" * 300
+            if k % 3 == 1 and 600 <= i < 850:      # 250-column deletion
+                q.append(0x2D); t.append(bb[i]); continue
+            if k % 3 == 2 and i == 299:            # an 'A' inserted in front of the homopolymer:
+                q += b"A" * 3; t += b"-" * 3       # the push slides it through 220 columns
+            q.append(bb[i]); t.append(bb[i])
+        extra.append((1, bytes(q), bytes(t)))
+    alns2 = [(1, bytes(bb[i] if rng.random() > 0.05 else 0x2D for i in range(tl)), bb) for _ in range(3)]
+    batch = batch_from_targets([(tl, alns + extra + alns2, bb)])
+    _check_batch(gpu_ctx_factory, batch, min_cov=0, min_len=0, trim=5, min_weight=0)
+    _check_batch(gpu_ctx_factory, batch, min_cov=6, min_len=500, trim=50)
+    # the a1 entry point alone, against the oracle strings
+    ctx = gpu_ctx_factory(min_cov=0, min_len=0, trim=0, min_weight=0)
+    got = ctx.normalize(extra, trim=7)
+    for (s, q, t), (gs, gq, gt) in zip(extra, got):
+        qn, tn = oracle.normalize_gaps(q, t)
+        assert (gq, gt, gs) == oracle.trim_aln(qn, tn, s, 7)
+
+
 def test_idempotent_reruns_same_context(gpu_ctx_factory):
     """Same context, same resident batch, run twice: identical output (no state leaks
     between runs, workspace reuse is clean)."""
