@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -171,6 +172,7 @@ void fill_params(Ctx *c, DgParams &p) {
     p.cns_tmp = (uint8_t *)c->d_cns_tmp.p; p.node_cap = c->node_cap;
     p.pool = (uint32_t *)c->d_pool.p; p.pool_cap = c->pool_cap;
     p.stk = (int32_t *)c->d_stk.p; p.stk_words = c->stk_words; p.growth_pct = c->growth_pct;
+    { const char *e = getenv("DAGCON_PF_AHEAD"); p.pf_ahead = e ? (uint32_t)atoi(e) : 48u; }
     p.cns = (uint8_t *)c->d_cns.p; p.cns_cap = c->cns_cap;
     p.cns_off = (uint64_t *)c->d_cns_off.p; p.cns_len = (uint32_t *)c->d_cns_len.p;
     p.seg_first = (uint64_t *)c->d_seg_first.p; p.n_seg = (uint32_t *)c->d_n_seg.p;
@@ -206,7 +208,7 @@ int launch_all(Ctx *c) {
         hipLaunchKernelGGL(k_groups, dim3(c->T, rows4), dim3(256), 0, s, p);
         hipLaunchKernelGGL(k_gscan, dim3(c->T), dim3(1024), 0, s, p);
         hipLaunchKernelGGL(k_init_nodes, dim3(c->T, (c->max_tlen + 2 + 255) / 256), dim3(256), 0, s, p);
-        if (c->A > 0) hipLaunchKernelGGL(k_emit, dim3((c->A + 63) / 64), dim3(64), 0, s, p);
+        if (c->A > 0) hipLaunchKernelGGL(k_emit, dim3(c->T, (c->max_k + 63) / 64), dim3(64), 0, s, p);
         const size_t lds = (size_t)4 * 2 * (c->max_k + 2) * sizeof(int32_t);
         if (lds > 65536)
             HIPCHK(c, hipFuncSetAttribute((const void *)k_lists, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -338,8 +340,8 @@ int dagcon_upload(dagcon_ctx *ctx, const dagcon_batch *b) {
             return fail(c, DAGCON_ERR_UNSUPPORTED, "tlen of target %u exceeds %u", t, 4u * 65535u - 2u);
         c->h_mat_base[t] = c->mat_cells;
         c->mat_cells += ((uint64_t)b->tlen[t] + 2) * k;
-        c->h_bbv_base[t] = c->sum_bb;
-        c->sum_bb += (uint64_t)b->tlen[t] + 2;
+        c->h_bbv_base[t] = c->sum_bb;                      // multiple of 4: 16-byte loads of bid[]
+        c->sum_bb += ((uint64_t)b->tlen[t] + 2 + 3) & ~3ull;
         if (c->have_bb) {
             c->h_bb_off[t] = b->backbone_off[t];
             bb_bytes = std::max<uint64_t>(bb_bytes, b->backbone_off[t] + b->tlen[t]);

@@ -121,6 +121,7 @@ struct DgParams {
     int32_t *stk;                  // per-target scratch, stk_words each
     uint32_t stk_words;
     uint32_t growth_pct;           // pool growth region as % of the initial adjacency words
+    uint32_t pf_ahead;             // vertices the prefetch wave runs ahead of the sweep (0 = off)
     // ---- outputs ----
     uint8_t *cns;
     uint64_t cns_cap;

@@ -58,7 +58,7 @@ __global__ __launch_bounds__(128) void k_bestpath(DgParams p) {
     if (threadIdx.x == 0) s_prog = (int)p.n_nodes[t] - 1;
     __syncthreads();
     if (threadIdx.x >= 64) {                             // wave 1: prefetcher, exit -> enter
-        dg_prefetch_wave(p.nodes + nb, p.pool + p.pool_base[t], p.pool_size[t], (int)p.n_nodes[t], &s_prog, lane, -1);
+        dg_prefetch_wave(p.nodes + nb, p.pool + p.pool_base[t], p.pool_size[t], (int)p.n_nodes[t], &s_prog, lane, -1, (int)p.pf_ahead);
         return;
     }
     DgNode *nd = p.nodes + nb;

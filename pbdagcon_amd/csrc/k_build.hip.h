@@ -467,17 +467,35 @@ __global__ __launch_bounds__(256) void k_init_nodes(DgParams p) {
 }
 
 // ---------------------------------------------------------------------------
-// k_emit: addAln, one lane per alignment.  Plain stores only.
+// k_emit: addAln.  One wave per (target, group of 64 reads), one lane per read.
+//
+// The lanes walk the backbone in lock step, 16 positions per batch.  In a batch a
+// lane first emits the insertion columns in front of a position and then its match
+// / deletion column; the arrival cell of the position stays in a register and the
+// departure cells in LDS, and the whole batch is written at its end as 16 + 16
+// row stores (K consecutive cells each: coalesced), with no load in between.
+// gfx950 counts stores in vmcnt, so a load behind a store waits for the store to
+// reach L2: keeping the stores of 16 positions together takes that wait off every
+// position.  Columns come 8 at a time (16-byte loads) into two 64-bit registers,
+// the backbone ids of the batch in four 16-byte loads.
 // ---------------------------------------------------------------------------
+#define DG_EB 16
+#define DG_ECOLS 48u          // columns staged in LDS per lane and batch (6 x 16 bytes)
+#define DG_ECOLS_STRIDE 50u   // 25 dwords per lane row: odd, lanes spread over banks
 __global__ __launch_bounds__(64) void k_emit(DgParams p) {
-    const uint32_t a = blockIdx.x * 64 + threadIdx.x;
-    if (a >= p.A) return;
+    __shared__ uint32_t s_D[DG_EB * 64];
+    __shared__ uint16_t s_col[64 * DG_ECOLS_STRIDE];
     if (dg_failed(p)) return;
-    const uint32_t t = p.aln_tgt[a];
+    const uint32_t t = blockIdx.x;
     if (!p.tactive[t]) return;
+    const int lane = threadIdx.x;
+    uint16_t *colw = s_col + lane * DG_ECOLS_STRIDE;
     const uint64_t ab = p.aln_begin[t];
-    const uint32_t r = (uint32_t)(a - ab);
     const uint32_t K = (uint32_t)(p.aln_begin[t + 1] - ab);
+    const uint32_t r = blockIdx.y * 64 + lane;
+    if (blockIdx.y * 64 >= K) return;
+    bool done = r >= K;
+    const uint32_t a = (uint32_t)(ab + (done ? 0 : r));
     const uint32_t blen = p.tlen[t];
     const uint32_t exitpos = blen + 1;
     const uint64_t nb = p.node_base[t];
@@ -488,80 +506,146 @@ __global__ __launch_bounds__(64) void k_emit(DgParams p) {
     const uint32_t *Cm = p.matC + p.mat_base[t];
     uint32_t *pool = p.pool + p.pool_base[t];
     const uint16_t *buf = p.norm + p.norm_off[a];
-    const uint32_t lo = p.n_lo[a], hi = p.n_hi[a];
-    uint32_t bbpos = p.n_start[a];
+    const uint32_t lo = done ? 0 : p.n_lo[a], hi = done ? 0 : p.n_hi[a];
+    uint32_t bbpos = done ? 0xFFFFFFFFu : p.n_start[a];
     uint32_t prev = 0;            // vertex id of the previous vertex on the read's path
     uint32_t prev_pos = 0;        // its backbone position (_bbMap for an inserted vertex)
     bool prev_bb = true;
-    uint32_t ins_id = 0, ins_pos = 0xFFFFFFFFu;   // next id inside the current insertion run
-
-    // departure of `prev` to `nxt`: a matrix cell for backbone vertices, the single out
-    // slot for an inserted vertex (its rank among inserted vertices is id - position)
+    uint32_t i = lo;
+    uint32_t c_base = 0x80000000u;                // first column staged in colw[] (nothing yet)
+    // columns [c_base, c_base + DG_ECOLS) of the lane sit in LDS; a batch normally needs
+    // ~18 of them, a long insertion run restages in place
+#define DG_STAGE(I)                                                                         \
+    do {                                                                                    \
+        c_base = (I) & ~7u;                                                                 \
+        const uint4 *src_ = reinterpret_cast<const uint4 *>(buf + c_base);                  \
+        uint4 v_[DG_ECOLS / 8];                                                             \
+        _Pragma("unroll") for (int k_ = 0; k_ < (int)(DG_ECOLS / 8); k_++)                  \
+            v_[k_] = (c_base + 8u * k_ < hi) ? src_[k_] : make_uint4(0, 0, 0, 0);           \
+        _Pragma("unroll") for (int k_ = 0; k_ < (int)(DG_ECOLS / 8); k_++) {                \
+            uint32_t *dst_ = reinterpret_cast<uint32_t *>(colw) + 4 * k_;                   \
+            dst_[0] = v_[k_].x; dst_[1] = v_[k_].y; dst_[2] = v_[k_].z; dst_[3] = v_[k_].w; \
+        }                                                                                   \
+    } while (0)
+#define DG_COLUMN(I, OUT)                                                                   \
+    do {                                                                                    \
+        if ((I) - c_base >= DG_ECOLS) DG_STAGE(I);                                          \
+        OUT = colw[(I) - c_base];                                                           \
+    } while (0)
+    // departure of `prev` to `nxt`: a matrix cell for backbone vertices (staged in LDS when
+    // its row belongs to this batch), the single out slot for an inserted vertex (its rank
+    // among inserted vertices is id - position)
 #define DG_DEPART(NXT)                                                       \
     do {                                                                     \
-        if (prev_bb) Dm[(uint64_t)prev_pos * K + r] = (NXT) + 1u;            \
-        else {                                                               \
+        if (prev_bb) {                                                       \
+            if (prev_pos >= pos0) s_D[(prev_pos - pos0) * 64 + lane] = (NXT) + 1u;   \
+            else Dm[(uint64_t)prev_pos * K + r] = (NXT) + 1u;                \
+        } else {                                                             \
             const uint32_t _rk = prev - prev_pos;                            \
             pool[3u * _rk] = (NXT);                                          \
             pool[3u * _rk + 1u] = 1u;                                        \
         }                                                                    \
     } while (0)
 
-    // backbone ids of 4 consecutive positions per 16-byte load (the cursor moves forward)
-    const uint32_t *bid_abs = p.bid;
-    uint64_t bid_q = ~0ull;
-    uint4 bid_v = make_uint4(0, 0, 0, 0);
-#define DG_EMIT_COL(c)                                                                             \
-    do {                                                                                           \
-        const uint8_t qb = DG_Q(c), tb = DG_T(c);                                                  \
-        if (qb == tb) { /* match (AlnGraphBoost.cpp:75-85) */                                      \
-            const uint64_t ax = bv + bbpos;                                                        \
-            if ((ax & ~3ull) != bid_q) { bid_q = ax & ~3ull; bid_v = *reinterpret_cast<const uint4 *>(bid_abs + bid_q); } \
-            const uint32_t k4 = (uint32_t)(ax & 3ull);                                             \
-            const uint32_t cur = k4 == 0 ? bid_v.x : k4 == 1 ? bid_v.y : k4 == 2 ? bid_v.z : bid_v.w; \
-            Am[(uint64_t)bbpos * K + r] = ((uint32_t)tb << 25) | (prev + 1u);                     \
-            DG_DEPART(cur);                                                                        \
-            prev = cur; prev_pos = bbpos; prev_bb = true;                                          \
-            bbpos++;                                                                               \
-        } else if (qb == DG_GAP) { /* deletion (:87-93) */                                         \
-            Am[(uint64_t)bbpos * K + r] = ((uint32_t)tb << 25) | DG_CELL_DEL;                      \
-            bbpos++;                                                                               \
-        } else if (tb == DG_GAP) { /* insertion (:95-104) */                                       \
-            if (ins_pos != bbpos) { ins_pos = bbpos; ins_id = gbase[bbpos] + Cm[(uint64_t)bbpos * K + r]; } \
-            const uint32_t id = ins_id++;                                                          \
-            const uint32_t rk = id - bbpos; /* bbpos backbone vertices precede group bbpos */      \
-            DgNode nd;                                                                             \
-            nd.out_len = 1; nd.in_len = 1; nd.base = qb; nd.flags = 0; nd.pad = 0;                 \
-            nd.weight = 1; nd.pending = 1;                                                         \
-            nd.out_off = 3u * rk; nd.in_off = 3u * rk + 2u; nd.out_cap = 1; nd.in_cap = 1;         \
-            nd.bbpos = (int32_t)bbpos;                                                             \
-            p.nodes[nb + id] = nd;                                                                 \
-            pool[3u * rk + 2u] = prev;                                                             \
-            DG_DEPART(id);                                                                         \
-            prev = id; prev_pos = bbpos; prev_bb = false;                                          \
-        }                                                                                          \
-    } while (0)
-
-    {
-        uint32_t i = lo;
-        while (i < hi && (i & 7u)) { const uint16_t c = buf[i++]; DG_EMIT_COL(c); }
-        while (i + 8 <= hi) {
-            const uint4 v = *reinterpret_cast<const uint4 *>(buf + i);
-            const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+    // first position of the wave (a multiple of 4 below it, for the 16-byte bid loads)
+    uint32_t pos0 = bbpos;
+    for (int o = 32; o > 0; o >>= 1) { const uint32_t x = (uint32_t)__shfl_xor((int)pos0, o); pos0 = x < pos0 ? x : pos0; }
+    pos0 &= ~3u;                                   // bbv_base is a multiple of 4
+    while (!__all(done)) {
+        // backbone ids of the batch: bid[pos0 .. pos0+15] (reads past tlen+1 stay inside the arena)
+        uint32_t bidv[DG_EB];
+        {
+            const uint4 *bp = reinterpret_cast<const uint4 *>(bid + pos0);
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const uint16_t c0 = (uint16_t)(w4[k] & 0xffffu), c1 = (uint16_t)(w4[k] >> 16);
-                DG_EMIT_COL(c0);
-                DG_EMIT_COL(c1);
+            for (int k = 0; k < DG_EB / 4; k++) {
+                const uint4 v = bp[k];
+                bidv[4 * k] = v.x; bidv[4 * k + 1] = v.y; bidv[4 * k + 2] = v.z; bidv[4 * k + 3] = v.w;
             }
-            i += 8;
         }
-        while (i < hi) { const uint16_t c = buf[i++]; DG_EMIT_COL(c); }
+        uint32_t gbv[DG_EB], cmv[DG_EB];
+        {
+            const uint4 *gp = reinterpret_cast<const uint4 *>(gbase + pos0);
+#pragma unroll
+            for (int k = 0; k < DG_EB / 4; k++) {
+                const uint4 v = gp[k];
+                gbv[4 * k] = v.x; gbv[4 * k + 1] = v.y; gbv[4 * k + 2] = v.z; gbv[4 * k + 3] = v.w;
+            }
+#pragma unroll
+            for (int j = 0; j < DG_EB; j++)
+                cmv[j] = (!done && pos0 + j <= exitpos) ? Cm[(uint64_t)(pos0 + j) * K + r] : 0u;
+        }
+        if (!done && i < hi && (i - c_base) + 24u > DG_ECOLS) DG_STAGE(i);
+        uint32_t acell[DG_EB];
+#pragma unroll
+        for (int j = 0; j < DG_EB; j++) { acell[j] = 0; s_D[j * 64 + lane] = 0; }
+        bool exit_cell = false;
+        uint32_t exit_val = 0;
+#pragma unroll
+        for (int j = 0; j < DG_EB; j++) {
+            const uint32_t pos = pos0 + j;
+            if (!done && bbpos == pos) {
+                // columns in front of this position that do not advance the backbone cursor:
+                // insertions (AlnGraphBoost.cpp:95-104); raw columns that match no branch are skipped
+                uint32_t ins_id = 0;
+                bool ins_open = false, have = false;
+                uint16_t c = 0;
+                while (i < hi) {
+                    DG_COLUMN(i, c);
+                    const uint8_t qb = DG_Q(c), tb = DG_T(c);
+                    if (qb == tb || qb == DG_GAP) { have = true; break; }
+                    if (tb == DG_GAP) {
+                        if (!ins_open) { ins_open = true; ins_id = gbv[j] + cmv[j]; }
+                        const uint32_t id = ins_id++;
+                        const uint32_t rk = id - bbpos;   // bbpos backbone vertices precede group bbpos
+                        DgNode nd;
+                        nd.out_len = 1; nd.in_len = 1; nd.base = qb; nd.flags = 0; nd.pad = 0;
+                        nd.weight = 1; nd.pending = 1;
+                        nd.out_off = 3u * rk; nd.in_off = 3u * rk + 2u; nd.out_cap = 1; nd.in_cap = 1;
+                        nd.bbpos = (int32_t)bbpos;
+                        p.nodes[nb + id] = nd;
+                        pool[3u * rk + 2u] = prev;
+                        DG_DEPART(id);
+                        prev = id; prev_pos = bbpos; prev_bb = false;
+                    }
+                    i++;
+                }
+                if (!have) {                              // :106 the read ends: edge to the exit vertex
+                    exit_cell = true; exit_val = prev + 1u;
+                    const uint32_t ex = bid[exitpos];
+                    DG_DEPART(ex);
+                    done = true;
+                } else {
+                    const uint8_t qb = DG_Q(c), tb = DG_T(c);
+                    if (qb == tb) {                       // match (:75-85)
+                        const uint32_t cur = bidv[j];
+                        acell[j] = ((uint32_t)tb << 25) | (prev + 1u);
+                        DG_DEPART(cur);
+                        prev = cur; prev_pos = bbpos; prev_bb = true;
+                    } else {                              // deletion (:87-93)
+                        acell[j] = ((uint32_t)tb << 25) | DG_CELL_DEL;
+                    }
+                    bbpos++;
+                    i++;
+                }
+            }
+        }
+        // the batch leaves as row stores; rows past the exit row do not exist
+        if (r < K) {
+#pragma unroll
+            for (int j = 0; j < DG_EB; j++) {
+                const uint32_t pos = pos0 + j;
+                if (pos <= blen) {
+                    Am[(uint64_t)pos * K + r] = acell[j];
+                    Dm[(uint64_t)pos * K + r] = s_D[j * 64 + lane];
+                }
+            }
+            if (exit_cell) Am[(uint64_t)exitpos * K + r] = exit_val;
+        }
+        pos0 += DG_EB;
     }
-#undef DG_EMIT_COL
-    Am[(uint64_t)exitpos * K + r] = prev + 1u;            // :106
-    DG_DEPART(bid[exitpos]);
 #undef DG_DEPART
+#undef DG_COLUMN
+#undef DG_STAGE
 }
 
 // ---------------------------------------------------------------------------

@@ -323,14 +323,15 @@ __device__ inline void dgg_merge_out(DgGraph &g, int n) {
 #define DG_PF_CHUNK 64
 
 __device__ inline void dg_prefetch_wave(const DgNode *nd, const uint32_t *pool, uint32_t pool_size,
-                                        int N, volatile int *s_prog, int lane, int dir) {
+                                        int N, volatile int *s_prog, int lane, int dir, int ahead) {
+    if (ahead <= 0) return;
     int next = dir > 0 ? 0 : N - 1;
     unsigned spins = 0;
     uint32_t sink = 0;
     for (;;) {
         const int cur = *s_prog;
         if (cur == DG_PROG_DONE) break;
-        const bool work = dir > 0 ? (next < N && next < cur + DG_PF_AHEAD) : (next >= 0 && next > cur - DG_PF_AHEAD);
+        const bool work = dir > 0 ? (next < N && next < cur + ahead) : (next >= 0 && next > cur - ahead);
         if (!work) {
             if ((dir > 0 ? next >= N : next < 0) || ++spins > 400000000u) break;
             __builtin_amdgcn_s_sleep(4);
@@ -682,7 +683,7 @@ __global__ __launch_bounds__(128) void k_merge(DgParams p) {
     if (threadIdx.x == 0) s_prog = 0;
     __syncthreads();
     if (threadIdx.x >= 64) {                             // wave 1: prefetcher
-        dg_prefetch_wave(p.nodes + nb, p.pool + p.pool_base[t], p.pool_size[t], (int)p.n_nodes[t], &s_prog, lane, +1);
+        dg_prefetch_wave(p.nodes + nb, p.pool + p.pool_base[t], p.pool_size[t], (int)p.n_nodes[t], &s_prog, lane, +1, (int)p.pf_ahead);
         return;
     }
     DgGraph g;
