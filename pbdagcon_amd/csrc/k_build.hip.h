@@ -700,11 +700,12 @@ __global__ __launch_bounds__(256) void k_lists(DgParams p) {
         if (dir == 0 && pos == blen + 1) continue;
         if (dir == 1 && pos == 0) continue;
         const uint32_t *row = dir == 0 ? Dm : Am;
+        // the list under construction: entry i on lane i while it fits a wave (K <= 62 always
+        // does), spilled to LDS beyond that
         int n = 1;
-        if (lane == 0) {
-            vals[0] = dir == 0 ? (int32_t)p.bid[bv + pos + 1] : (int32_t)p.bid[bv + pos - 1];
-            cnts[0] = 0;
-        }
+        int32_t lv = dir == 0 ? (int32_t)p.bid[bv + pos + 1] : (int32_t)p.bid[bv + pos - 1];
+        int32_t lc = 0;
+        bool in_lds = false;
         for (uint32_t r0 = 0; r0 < K; r0 += DG_WAVE) {
             const uint32_t r = r0 + lane;
             const uint32_t cell = r < K ? row[r] : 0u;
@@ -726,12 +727,26 @@ __global__ __launch_bounds__(256) void k_lists(DgParams p) {
                 const unsigned long long same = __ballot(val == x);
                 rem &= ~same;
                 const int c = __popcll(same);
-                const int idx = dg_lds_find(vals, n, x - 1, lane);
-                if (idx >= 0) {
-                    if (lane == 0) cnts[idx] += c;
-                } else {
-                    if (lane == 0) { vals[n] = x - 1; cnts[n] = c; }
-                    n++;
+                if (!in_lds) {
+                    const unsigned long long hit = __ballot(lane < n && lv == x - 1);
+                    if (hit) {
+                        if (lane == __ffsll((long long)hit) - 1) lc += c;
+                    } else if (n < DG_WAVE) {
+                        if (lane == n) { lv = x - 1; lc = c; }
+                        n++;
+                    } else {
+                        vals[lane] = lv; cnts[lane] = lc;      // 64 entries so far: continue in LDS
+                        in_lds = true;
+                    }
+                }
+                if (in_lds) {
+                    const int idx = dg_lds_find(vals, n, x - 1, lane);
+                    if (idx >= 0) {
+                        if (lane == 0) cnts[idx] += c;
+                    } else {
+                        if (lane == 0) { vals[n] = x - 1; cnts[n] = c; }
+                        n++;
+                    }
                 }
             }
         }
@@ -743,9 +758,16 @@ __global__ __launch_bounds__(256) void k_lists(DgParams p) {
             if (off == 0xFFFFFFFFu) return;
             if (dir == 0) { out_off = off; out_cap = cap; } else { in_off = off; in_cap = cap; }
         }
-        for (int i = lane; i < n; i += DG_WAVE) {
-            if (dir == 0) { pool[off + 2 * i] = (uint32_t)vals[i]; pool[off + 2 * i + 1] = (uint32_t)cnts[i]; }
-            else pool[off + i] = (uint32_t)vals[i];
+        if (!in_lds) {
+            if (lane < n) {
+                if (dir == 0) { pool[off + 2 * lane] = (uint32_t)lv; pool[off + 2 * lane + 1] = (uint32_t)lc; }
+                else pool[off + lane] = (uint32_t)lv;
+            }
+        } else {
+            for (int i = lane; i < n; i += DG_WAVE) {
+                if (dir == 0) { pool[off + 2 * i] = (uint32_t)vals[i]; pool[off + 2 * i + 1] = (uint32_t)cnts[i]; }
+                else pool[off + i] = (uint32_t)vals[i];
+            }
         }
         if (dir == 0) out_len = (uint32_t)n; else in_len = (uint32_t)n;
     }
