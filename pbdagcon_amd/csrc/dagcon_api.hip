@@ -220,7 +220,7 @@ int launch_all(Ctx *c) {
     HIPCHK(c, hipEventRecord(c->ev[3], s));
     if (c->T > 0 && !(c->opts.flags & (DAGCON_FLAG_STOP_AFTER_BUILD | DAGCON_FLAG_STOP_AFTER_MERGE))) {
         hipLaunchKernelGGL(k_bp_prepare, dim3(c->T, 16), dim3(256), 0, s, p);
-        hipLaunchKernelGGL(k_bestpath, dim3(c->T), dim3(128), 0, s, p);
+        hipLaunchKernelGGL(k_bestpath, dim3(c->T), dim3(64), 0, s, p);
     }
     HIPCHK(c, hipEventRecord(c->ev[4], s));
     HIPCHK(c, hipGetLastError());

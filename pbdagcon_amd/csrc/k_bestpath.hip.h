@@ -10,13 +10,20 @@
 //   k_bp_prepare  thread per vertex: the per-target term of the edge score
 //                 (pen = coverage[bbMap[t]]*0.5, or the "-10" marker), score = 0
 //                 (std::map default), pending = out-degree
-//   k_bestpath    wave per target: Kahn sweep from the exit vertex, one vertex per
-//                 step, one list entry per lane (out entries on lanes 0-31, in
-//                 entries on lanes 32-63): gather (score, pen) of the successors,
-//                 wave max with lowest-lane tie-break (= first maximum in list
-//                 order), release the predecessors with plain stores (one wave
-//                 owns the target, no atomics); then the best-edge walk and the
-//                 segmentation.
+//   k_bestpath    one wave per target.  Vertex ids are in backbone-position order,
+//                 which is a topological order of the graph except for the few edges
+//                 the merge turned around.  The wave therefore STREAMS the vertices
+//                 from the exit downwards: 64 records at a time are loaded two chunks
+//                 ahead (plain loads whose latency nobody waits for), unpacked into an
+//                 LDS ring of the last 256 vertices (score, pen, pending, the adjacency
+//                 entries), and every step works on LDS only: the successors' (score,
+//                 pen) come from the ring, the pending counters of the predecessors are
+//                 decremented in the ring.  A vertex whose pending counter is not zero
+//                 when the stream reaches it (a turned-around edge) waits and is taken
+//                 up the moment its last successor is scored (Kahn's rule), so the
+//                 order is always reverse-topological.  Whatever does not fit the ring
+//                 (long lists, far-away neighbours) goes through HBM.
+//                 Then the best-edge walk and the segmentation.
 //
 // fp32 throughout; every value is a multiple of 0.5 below 2^23, so the
 // arithmetic is exact and the expression order of the reference is kept
@@ -48,103 +55,250 @@ __global__ __launch_bounds__(256) void k_bp_prepare(DgParams p) {
     }
 }
 
-__global__ __launch_bounds__(128) void k_bestpath(DgParams p) {
+#define DG_BR 256            // ring slots (vertex id & 255)
+#define DG_BOUT 6            // out entries kept in a slot
+#define DG_BIN 8             // in entries kept in a slot
+#define DG_BDEF 64           // waiting vertices that became ready
+#define DG_BL_HBM 0x80000000 // lens: the lists did not fit the slot, read them from HBM
+
+struct DgBpShared {
+    int tag[DG_BR];
+    float score[DG_BR];
+    float pen[DG_BR];
+    int pend[DG_BR];
+    int lens[DG_BR];                     // out_len | in_len << 8 | flags << 16 | DG_BL_HBM
+    int out_dst[DG_BR * DG_BOUT];
+    unsigned short out_cnt[DG_BR * DG_BOUT];
+    int in_src[DG_BR * DG_BIN];
+    int delta[DG_BR];                    // decrements for vertices that are not in the ring yet
+    int defer[DG_BDEF];
+};
+
+// one predecessor loses an unvisited out-edge (AlnGraphBoost.cpp:423-439); returns true when
+// it became ready although the stream has already passed it
+__device__ __forceinline__ bool dg_bp_release(DgBpShared &S, DgNode *nd, int s, int stream_pos) {
+    const int x = s & (DG_BR - 1);
+    const int tg = S.tag[x], pv = S.pend[x];               // one LDS trip for both
+    if (tg == s) {
+        const int pnd = pv - 1;
+        S.pend[x] = pnd;
+        return pnd == 0 && s > stream_pos;
+    }
+    if (s <= stream_pos && s > stream_pos - DG_BR) {       // about to be staged: remember
+        S.delta[x] += 1;
+        return false;
+    }
+    const int pnd = nd[s].pending - 1;                      // far away: HBM
+    nd[s].pending = pnd;
+    return pnd == 0 && s > stream_pos;
+}
+
+__global__ __launch_bounds__(64) void k_bestpath(DgParams p) {
     const uint32_t t = blockIdx.x;
     if (dg_failed(p) || !p.tactive[t]) return;
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x;
     const uint64_t nb = p.node_base[t];
-    __shared__ int s_prog;
+    __shared__ DgBpShared S;
     __shared__ uint32_t s_len, s_nseg;
-    if (threadIdx.x == 0) s_prog = (int)p.n_nodes[t] - 1;
-    __syncthreads();
-    if (threadIdx.x >= 64) {                             // wave 1: prefetcher, exit -> enter
-        dg_prefetch_wave(p.nodes + nb, p.pool + p.pool_base[t], p.pool_size[t], (int)p.n_nodes[t], &s_prog, lane, -1, (int)p.pf_ahead);
-        return;
-    }
     DgNode *nd = p.nodes + nb;
     int32_t *best = p.best + nb;
-    int32_t *queue = p.queue + nb;
     float2 *score = p.score + nb;
     const uint32_t *pool = p.pool + p.pool_base[t];
-    const uint32_t N = p.n_nodes[t];
-    const int exitv = (int)N - 1;
+    const int N = (int)p.n_nodes[t];
+    const int exitv = N - 1;
 
-    if (lane == 0) queue[0] = exitv;
-    DG_WAVE_FENCE();
-    uint32_t qh = 0, qt = 1;
+    for (int i = lane; i < DG_BR; i += 64) { S.tag[i] = -1; S.delta[i] = 0; S.pend[i] = 0; }
+
+    // ---- staging registers: r_* = records of a chunk, e_* = its list entries ----
+    uint4 r_lo, r_hi, n_lo, n_hi;
+    float r_pen, n_pen;
+    int e_out[DG_BOUT], e_cnt[DG_BOUT], e_in[DG_BIN];
+    // chunk c holds ids [N-1-64c-63, N-1-64c]; lane l -> id N-1-64c-l
+#define DG_LOAD_REC(C, LO, HI, PEN)                                                        \
+    do {                                                                                    \
+        const int v_ = N - 1 - 64 * (C) - lane;                                             \
+        LO = make_uint4(0, 0, 0, 0); HI = make_uint4(0, 0, 0, 0); PEN = 0.0f;               \
+        if (v_ >= 0) {                                                                      \
+            LO = *reinterpret_cast<const uint4 *>(&nd[v_]);                                 \
+            HI = *(reinterpret_cast<const uint4 *>(&nd[v_]) + 1);                           \
+            PEN = score[v_].y;                                                              \
+        }                                                                                   \
+    } while (0)
+#define DG_LOAD_ENT(LO, HI)                                                                 \
+    do {                                                                                    \
+        const int ol_ = (int)((LO).x & 0xffffu), il_ = (int)((LO).x >> 16);                 \
+        const bool fit_ = ol_ <= DG_BOUT && il_ <= DG_BIN;                                  \
+        _Pragma("unroll") for (int k_ = 0; k_ < DG_BOUT; k_++) {                            \
+            e_out[k_] = 0; e_cnt[k_] = 0;                                                   \
+            if (fit_ && k_ < ol_) { e_out[k_] = (int)pool[(HI).x + 2 * k_]; e_cnt[k_] = (int)pool[(HI).x + 2 * k_ + 1]; } \
+        }                                                                                   \
+        _Pragma("unroll") for (int k_ = 0; k_ < DG_BIN; k_++) {                             \
+            e_in[k_] = 0;                                                                   \
+            if (fit_ && k_ < il_) e_in[k_] = (int)pool[(HI).y + k_];                        \
+        }                                                                                   \
+    } while (0)
+    // unpack chunk C (records LO/PEN + entries) into the ring; a slot that still holds a
+    // vertex waiting for its successors hands its counter back to HBM
+#define DG_WRITE_CHUNK(C, LO, PEN)                                                          \
+    do {                                                                                    \
+        const int v_ = N - 1 - 64 * (C) - lane;                                             \
+        if (v_ >= 0) {                                                                      \
+            const int x_ = v_ & (DG_BR - 1);                                                \
+            const int old_ = S.tag[x_];                                                     \
+            if (old_ >= 0 && S.pend[x_] > 0) nd[old_].pending = S.pend[x_];                 \
+            const int ol_ = (int)((LO).x & 0xffffu), il_ = (int)((LO).x >> 16);             \
+            const bool fit_ = ol_ <= DG_BOUT && il_ <= DG_BIN;                              \
+            S.tag[x_] = v_;                                                                 \
+            S.score[x_] = 0.0f;                                                             \
+            S.pen[x_] = PEN;                                                                \
+            S.pend[x_] = (int)(LO).w - S.delta[x_];                                         \
+            S.delta[x_] = 0;                                                                \
+            S.lens[x_] = (fit_ ? (ol_ | (il_ << 8)) : (int)DG_BL_HBM) | (int)(((LO).y >> 8) & 0xffu) << 16; \
+            if (fit_) {                                                                     \
+                _Pragma("unroll") for (int k_ = 0; k_ < DG_BOUT; k_++) {                    \
+                    S.out_dst[x_ * DG_BOUT + k_] = e_out[k_];                               \
+                    S.out_cnt[x_ * DG_BOUT + k_] = (unsigned short)e_cnt[k_];               \
+                }                                                                           \
+                _Pragma("unroll") for (int k_ = 0; k_ < DG_BIN; k_++) S.in_src[x_ * DG_BIN + k_] = e_in[k_]; \
+            }                                                                               \
+        }                                                                                   \
+    } while (0)
+
+    const int n_chunks = (N + 63) / 64;
+    // prologue: chunk 0 into the ring; chunk 1 records + entries, chunk 2 records in flight
+    DG_LOAD_REC(0, r_lo, r_hi, r_pen);
+    DG_LOAD_ENT(r_lo, r_hi);
+    DG_WRITE_CHUNK(0, r_lo, r_pen);
+    DG_LOAD_REC(1, r_lo, r_hi, r_pen);
+    DG_LOAD_ENT(r_lo, r_hi);
+    DG_LOAD_REC(2, n_lo, n_hi, n_pen);
+
+    int n_defer = 0;
     bool bad = false;
-    int prog = exitv;
-    while (qh < qt) {
-        const int n = queue[qh++];
-        if (n < prog) { prog = n; if (lane == 0) *(volatile int *)&s_prog = n; }
-        const DgNode nn = nd[n];
-        const int out_len = nn.out_len, in_len = nn.in_len;
-        if (out_len <= 32 && in_len <= 32) {
-            const bool is_out = lane < 32;
-            const int idx = lane & 31;
-            const bool valid = is_out ? idx < out_len : idx < in_len;
-            int nbr = 0, cnt = 0;
-            if (valid) {
-                if (is_out) { nbr = (int)pool[nn.out_off + 2 * idx]; cnt = (int)pool[nn.out_off + 2 * idx + 1]; }
-                else nbr = (int)pool[nn.in_off + idx];
-            }
-            float ns = -FLT_MAX;
-            int pend = 0;
-            if (valid) {
-                if (is_out) {
-                    const float2 sp = score[nbr];
-                    if (sp.y == DG_PEN_BACKBONE_ONLY) ns = sp.x - 10.0f;
-                    else ns = (float)cnt - sp.y + sp.x;
-                } else {
-                    pend = nd[nbr].pending - 1;
-                    nd[nbr].pending = pend;
-                }
-            }
-            // :399-416 first maximum in list order: the out entries sit on lanes 0..out_len-1 in
-            // list order, so a scalar walk over them with strict '>' is the reference loop
-            if (out_len > 0) {
-                float mx = -FLT_MAX;
-                int bd = -1;
-                for (int i = 0; i < out_len; i++) {
-                    const float x = __int_as_float(DG_RL(__float_as_int(ns), i));
-                    if (x > mx) { mx = x; bd = DG_RL(nbr, i); }
-                }
-                if (lane == 0 && bd >= 0) { score[n].x = mx; best[n] = bd; }
-            }
-            const unsigned long long rm = __ballot(valid && !is_out && pend == 0);
-            if (valid && !is_out && pend == 0) {
-                const uint32_t pos = qt + (uint32_t)__popcll(rm & ((1ull << lane) - 1ull));
-                if (pos < N) queue[pos] = nbr;
-            }
-            qt += (uint32_t)__popcll(rm);
-        } else {
-            // a list longer than half a wave: literal loops on lane 0
-            uint32_t nqt = qt;
-            if (lane == 0) {
-                float bs = -FLT_MAX;
-                int bd = -1;
-                for (int i = 0; i < out_len; i++) {
-                    const int d = (int)pool[nn.out_off + 2 * i];
-                    const int c = (int)pool[nn.out_off + 2 * i + 1];
-                    const float2 sp = score[d];
-                    const float ns = sp.y == DG_PEN_BACKBONE_ONLY ? sp.x - 10.0f : (float)c - sp.y + sp.x;
-                    if (ns > bs) { bs = ns; bd = d; }
-                }
-                if (bd >= 0) { score[n].x = bs; best[n] = bd; }
-                for (int i = 0; i < in_len; i++) {
-                    const int s = (int)pool[nn.in_off + i];
-                    const int pend = nd[s].pending - 1;
-                    nd[s].pending = pend;
-                    if (pend == 0 && nqt < N) queue[nqt++] = s;
-                }
-            }
-            DG_WAVE_FENCE();
-            qt = (uint32_t)DG_RL(nqt, 0);
+    for (int c = 0; c < n_chunks && !bad; c++) {
+        if (c > 0) {
+            // chunk c: its records and entries were requested a whole chunk ago
+            DG_WRITE_CHUNK(c, r_lo, r_pen);
+            r_lo = n_lo; r_hi = n_hi; r_pen = n_pen;
+            DG_LOAD_ENT(r_lo, r_hi);                       // chunk c+1
+            DG_LOAD_REC(c + 2, n_lo, n_hi, n_pen);         // chunk c+2
         }
-        if (qt > N) { bad = true; break; }
+        const int v_hi = N - 1 - 64 * c;
+        const int v_lo = v_hi - 63 < 0 ? 0 : v_hi - 63;
+        int v = v_hi;
+        while (v >= v_lo || n_defer > 0) {
+            int n, from_defer;
+            if (n_defer > 0) { n = S.defer[--n_defer]; from_defer = 1; }
+            else { n = v--; from_defer = 0; }
+            n = __builtin_amdgcn_readfirstlane(n);
+            const int stream_pos = v;                     // ids > v have had their turn
+            const int x = n & (DG_BR - 1);
+            // tag, lens and pending in one LDS trip
+            const int tg_ = S.tag[x], ln_ = S.lens[x], pd_ = S.pend[x];
+            const bool in_ring = __builtin_amdgcn_readfirstlane(tg_) == n;
+            int lens, pend_n;
+            if (in_ring) {
+                lens = __builtin_amdgcn_readfirstlane(ln_);
+                pend_n = __builtin_amdgcn_readfirstlane(pd_);
+            } else {
+                // a waiting vertex that fell out of the ring: everything from HBM
+                const uint4 lo = *reinterpret_cast<const uint4 *>(&nd[n]);
+                lens = __builtin_amdgcn_readfirstlane((int)DG_BL_HBM | (int)((lo.y >> 8) & 0xffu) << 16);
+                pend_n = __builtin_amdgcn_readfirstlane((int)lo.w);
+            }
+            if ((lens >> 16) & DG_NF_DELETED) continue;
+            if (!from_defer && pend_n != 0) continue;     // waits for a turned-around edge
+            int out_len = lens & 0xff, in_len = (lens >> 8) & 0xff;
+            const bool hbm = lens < 0;
+            uint32_t out_off = 0, in_off = 0;
+            if (hbm) {
+                const DgNode nn = nd[n];
+                out_off = __builtin_amdgcn_readfirstlane(nn.out_off);
+                in_off = __builtin_amdgcn_readfirstlane(nn.in_off);
+                out_len = __builtin_amdgcn_readfirstlane((int)nn.out_len);
+                in_len = __builtin_amdgcn_readfirstlane((int)nn.in_len);
+            }
+            if (out_len <= 32 && in_len <= 32) {
+                const bool is_out = lane < 32;
+                const int idx = lane & 31;
+                const bool valid = is_out ? idx < out_len : idx < in_len;
+                int nbr = 0, cnt = 0;
+                if (valid) {
+                    if (!hbm) {
+                        if (is_out) { nbr = S.out_dst[x * DG_BOUT + idx]; cnt = S.out_cnt[x * DG_BOUT + idx]; }
+                        else nbr = S.in_src[x * DG_BIN + idx];
+                    } else {
+                        if (is_out) { nbr = (int)pool[out_off + 2 * idx]; cnt = (int)pool[out_off + 2 * idx + 1]; }
+                        else nbr = (int)pool[in_off + idx];
+                    }
+                }
+                float ns = -FLT_MAX;
+                if (valid && is_out) {
+                    const int y = nbr & (DG_BR - 1);
+                    const int tg = S.tag[y];
+                    float sc = S.score[y], pn = S.pen[y];           // one LDS trip for all three
+                    if (tg != nbr) { const float2 sp = score[nbr]; sc = sp.x; pn = sp.y; }
+                    if (pn == DG_PEN_BACKBONE_ONLY) ns = sc - 10.0f;
+                    else ns = (float)cnt - pn + sc;
+                }
+                // :399-416 first maximum in list order: the out entries sit on lanes
+                // 0..out_len-1 in list order; a scalar walk with strict '>' is the reference loop
+                if (out_len > 0) {
+                    float mx = -FLT_MAX;
+                    int bd = -1;
+                    for (int i = 0; i < out_len; i++) {
+                        const float xs = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ns), i));
+                        if (xs > mx) { mx = xs; bd = __builtin_amdgcn_readlane(nbr, i); }
+                    }
+                    if (lane == 0 && bd >= 0) {
+                        if (in_ring) S.score[x] = mx;
+                        score[n].x = mx;
+                        best[n] = bd;
+                    }
+                }
+                bool rdy = false;
+                if (valid && !is_out) rdy = dg_bp_release(S, nd, nbr, stream_pos);
+                const unsigned long long rm = __ballot(rdy);
+                if (rm) {
+                    if (n_defer + __popcll(rm) > DG_BDEF) { bad = true; break; }
+                    if (rdy) S.defer[n_defer + __popcll(rm & ((1ull << lane) - 1ull))] = nbr;
+                    n_defer += __popcll(rm);
+                }
+            } else {
+                // a list longer than half a wave: literal loops on lane 0
+                int nd_new = n_defer;
+                if (lane == 0) {
+                    float bs = -FLT_MAX;
+                    int bd = -1;
+                    for (int i = 0; i < out_len; i++) {
+                        const int d = (int)pool[out_off + 2 * i];
+                        const int cc = (int)pool[out_off + 2 * i + 1];
+                        const int y = d & (DG_BR - 1);
+                        float sc, pn;
+                        if (S.tag[y] == d) { sc = S.score[y]; pn = S.pen[y]; }
+                        else { const float2 sp = score[d]; sc = sp.x; pn = sp.y; }
+                        const float nsx = pn == DG_PEN_BACKBONE_ONLY ? sc - 10.0f : (float)cc - pn + sc;
+                        if (nsx > bs) { bs = nsx; bd = d; }
+                    }
+                    if (bd >= 0) { if (in_ring) S.score[x] = bs; score[n].x = bs; best[n] = bd; }
+                    for (int i = 0; i < in_len; i++) {
+                        const int s = (int)pool[in_off + i];
+                        if (dg_bp_release(S, nd, s, stream_pos)) {
+                            if (nd_new < DG_BDEF) S.defer[nd_new] = s;
+                            nd_new++;
+                        }
+                    }
+                }
+                n_defer = __builtin_amdgcn_readlane(nd_new, 0);
+                if (n_defer > DG_BDEF) { bad = true; break; }
+            }
+        }
     }
-    if (lane == 0) *(volatile int *)&s_prog = DG_PROG_DONE;
+#undef DG_LOAD_REC
+#undef DG_LOAD_ENT
+#undef DG_WRITE_CHUNK
     if (bad) { if (lane == 0) dg_fail(p, DG_E_INTERNAL); return; }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 
     // :443-456 walk the best edges from enter; :327-373 segmentation.  The walk
     // is a pointer chase; lane 0 does it and keeps the consensus in cns_tmp.
@@ -179,7 +333,7 @@ __global__ __launch_bounds__(128) void k_bestpath(DgParams p) {
             }
             if (nxt < 0) break;
             v = nxt;
-            if (++steps > N) { ovf = true; break; }
+            if (++steps > (uint32_t)N) { ovf = true; break; }
         }
         if (met && (uint32_t)(idx - offs) >= minlen) {
             if (nseg < seg_cap) { segs[2 * nseg] = offs; segs[2 * nseg + 1] = idx; nseg++; }
@@ -195,7 +349,7 @@ __global__ __launch_bounds__(128) void k_bestpath(DgParams p) {
         p.seg_first[t] = so; p.n_seg[t] = nseg;
         s_len = keep; s_nseg = nseg;
     }
-    DG_WAVE_FENCE();
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     const uint32_t keep = s_len, nseg = s_nseg;
     uint8_t *out = p.cns + p.cns_off[t];
     for (uint32_t i = lane; i < keep; i += 64) out[i] = tmp[i];
