@@ -1,0 +1,261 @@
+// pbdagcon_main.cpp -- `pbdagcon`-compatible command line on top of the C ABI.
+//
+// Replaces the Reader -> N x Consensus -> Writer thread pipeline of the reference
+// (src/cpp/main.cpp:37-176, 227-288) with: parse the BLASR -m 5 stream, group
+// consecutive records by target id (BlasrM5AlnProvider.cpp:34-55), hand batches of
+// independent targets to dagcon_consensus() (include/dagcon.h), print FASTA records in
+// input order (main.cpp:141-143).  Same flags and defaults as main.cpp:178-225.
+//
+// Differences that are deliberate and documented in DESIGN.md:
+//   * output order is input order (the reference's is nondeterministic for -j >= 2, Q3);
+//   * -j is accepted and ignored (parallelism is the GPU's), -j 1 does not deadlock (Q2);
+//   * -a (re-align .pre input through blasr_libcpp) is refused: that library is absent;
+//   * blank lines are skipped (the reference duplicates the previous record, Q9);
+//   * a missing input file is an error on stderr, exit 1 (the reference is silent, Q11).
+#include <cerrno>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include "../../../include/dagcon.h"
+
+namespace {
+
+struct Opts {
+    unsigned threads = 4, min_cov = 6, min_len = 500, trim = 50;
+    bool align = false, verbose = false, dump = false;
+    size_t batch_targets = 2048;
+    size_t batch_bytes = 1ull << 30;
+    std::string input;
+};
+
+void usage(FILE *f) {
+    fprintf(f,
+            "USAGE: pbdagcon [-j <int>] [-c <uint>] [-m <uint>] [-t <uint>] [-a] [-v] <input>\n"
+            "  PBDAGCON is a tool that implements DAGCon (Directed Acyclic Graph Consensus); this build\n"
+            "  runs the consensus on an MI355X through libdagcon_hip.so.\n"
+            "  -j, --threads       accepted for compatibility (default 4)\n"
+            "  -c, --min-coverage  minimum alignments per target, also the minimum node weight (default 6)\n"
+            "  -m, --min-length    minimum alignment / consensus length (default 500)\n"
+            "  -t, --trim          trim alignments on either side (default 50)\n"
+            "  -a, --align         not available in this build (needs blasr_libcpp)\n"
+            "  -v, --verbose       per-target progress on stderr\n"
+            "  <input>             BLASR -m 5 file sorted by target, or - for stdin\n"
+            "  version 0.3 (dagcon-mi355x)\n");
+}
+
+bool parse_uint(const char *s, unsigned *out) {
+    char *e = nullptr;
+    errno = 0;
+    unsigned long v = strtoul(s, &e, 10);
+    if (errno || !e || *e || v > 0xFFFFFFFFul) return false;
+    *out = (unsigned)v;
+    return true;
+}
+
+int parse_args(int argc, char **argv, Opts &o) {
+    for (int i = 1; i < argc; i++) {
+        std::string a = argv[i];
+        auto need = [&](unsigned *dst) {
+            if (i + 1 >= argc || !parse_uint(argv[i + 1], dst)) { fprintf(stderr, "PARSE ERROR: %s needs an unsigned integer\n", a.c_str()); return false; }
+            i++;
+            return true;
+        };
+        if (a == "-j" || a == "--threads") { if (!need(&o.threads)) return 2; }
+        else if (a == "-c" || a == "--min-coverage") { if (!need(&o.min_cov)) return 2; }
+        else if (a == "-m" || a == "--min-length") { if (!need(&o.min_len)) return 2; }
+        else if (a == "-t" || a == "--trim") { if (!need(&o.trim)) return 2; }
+        else if (a == "-a" || a == "--align") o.align = true;
+        else if (a == "-v" || a == "--verbose") o.verbose = true;
+        else if (a == "--dump-parsed") o.dump = true;            // test hook: parser only, no GPU
+        else if (a == "-h" || a == "--help") { usage(stdout); exit(0); }
+        else if (a == "--version") { printf("pbdagcon  version: 0.3\n"); exit(0); }
+        else if (a == "-" || a[0] != '-') {
+            if (!o.input.empty()) { fprintf(stderr, "PARSE ERROR: more than one input\n"); return 2; }
+            o.input = a;
+        } else { fprintf(stderr, "PARSE ERROR: unknown argument %s\n", a.c_str()); return 2; }
+    }
+    if (o.input.empty()) { fprintf(stderr, "PARSE ERROR: required argument missing: input\n"); usage(stderr); return 2; }
+    return 0;
+}
+
+// Alignment.cpp:15-26: only upper-case ACGT are complemented, then the string is reversed
+void revcomp_append(std::string &dst, const char *s, size_t n) {
+    size_t base = dst.size();
+    dst.resize(base + n);
+    for (size_t i = 0; i < n; i++) {
+        char c = s[n - 1 - i];
+        dst[base + i] = c == 'T' ? 'A' : c == 'G' ? 'C' : c == 'A' ? 'T' : c == 'C' ? 'G' : c;
+    }
+}
+
+// istringstream >> uint32_t on a token (Alignment.cpp:63-66)
+uint32_t tok_u32(const char *s, size_t n) {
+    uint64_t v = 0;
+    size_t i = 0;
+    bool any = false, over = false, neg = false;
+    if (i < n && (s[i] == '+' || s[i] == '-')) { neg = s[i] == '-'; i++; }
+    for (; i < n && s[i] >= '0' && s[i] <= '9'; i++) {
+        if (!over) v = v * 10 + (uint64_t)(s[i] - '0');
+        if (v > 0xFFFFFFFFull) over = true;
+        any = true;
+    }
+    if (!any) return 0;
+    if (over) return 0xFFFFFFFFu;
+    return neg ? (uint32_t)(0u - (uint32_t)v) : (uint32_t)v;
+}
+
+struct Batch {
+    std::vector<std::string> ids;
+    std::vector<uint32_t> tlen, start, len;
+    std::vector<uint64_t> begin{0}, off;
+    std::string q, t;
+    void clear() { ids.clear(); tlen.clear(); start.clear(); len.clear(); begin.assign(1, 0); off.clear(); q.clear(); t.clear(); }
+};
+
+int flush(dagcon_ctx *ctx, Batch &b, const Opts &o) {
+    if (b.ids.empty()) return 0;
+    if (b.begin.back() != b.start.size()) b.begin.push_back(b.start.size());
+    dagcon_batch db;
+    memset(&db, 0, sizeof db);
+    db.n_targets = (uint32_t)b.ids.size();
+    db.tlen = b.tlen.data(); db.aln_begin = b.begin.data();
+    db.aln_start = b.start.data(); db.aln_off = b.off.data(); db.aln_len = b.len.data();
+    db.qstr = b.q.data(); db.tstr = b.t.data(); db.blob_bytes = b.q.size();
+    dagcon_results r;
+    int rc = dagcon_consensus(ctx, &db, &r);
+    if (rc != DAGCON_OK) {
+        fprintf(stderr, "pbdagcon: consensus failed (%d): %s\n", rc, dagcon_last_error(ctx));
+        return 1;
+    }
+    for (uint32_t g = 0; g < r.n_targets; g++) {
+        if (o.verbose)
+            fprintf(stderr, "Consensus calling: %s Alignments: %llu\n", b.ids[g].c_str(),
+                    (unsigned long long)(b.begin[g + 1] - b.begin[g]));
+        for (uint64_t s = r.seg_begin[g]; s < r.seg_begin[g + 1]; s++) {
+            // main.cpp:141-143  ">%s/%d_%d\n%s\n"
+            printf(">%s/%d_%d\n", b.ids[g].c_str(), r.range0[s], r.range1[s]);
+            fwrite(r.seq_blob + r.seq_off[s], 1, r.seq_len[s], stdout);
+            fputc('\n', stdout);
+        }
+    }
+    b.clear();
+    return 0;
+}
+
+}  // namespace
+
+int main(int argc, char **argv) {
+    Opts o;
+    if (int rc = parse_args(argc, argv, o)) return rc;
+    if (o.align) {
+        fprintf(stderr, "pbdagcon: -a/--align needs blasr_libcpp (SimpleAligner.cpp), which this build does not have;\n"
+                        "          give it aligned -m 5 input instead\n");
+        return 2;
+    }
+    // ---- input: mmap a file, or slurp stdin ----
+    const char *data = nullptr;
+    size_t size = 0;
+    std::string slurp;
+    void *map = nullptr;
+    if (o.input == "-") {
+        char buf[1 << 16];
+        size_t n;
+        while ((n = fread(buf, 1, sizeof buf, stdin)) > 0) slurp.append(buf, n);
+        data = slurp.data(); size = slurp.size();
+    } else {
+        int fd = open(o.input.c_str(), O_RDONLY);
+        if (fd < 0) { fprintf(stderr, "pbdagcon: error opening file: %s\n", o.input.c_str()); return 1; }
+        struct stat st;
+        if (fstat(fd, &st) != 0) { close(fd); return 1; }
+        size = (size_t)st.st_size;
+        if (size) {
+            map = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (map == MAP_FAILED) { fprintf(stderr, "pbdagcon: mmap failed\n"); close(fd); return 1; }
+            data = (const char *)map;
+        }
+        close(fd);
+    }
+
+    dagcon_ctx *ctx = nullptr;
+    if (!o.dump) {
+        dagcon_opts dopt;
+        dagcon_default_opts(&dopt);
+        dopt.min_cov = o.min_cov; dopt.min_len = o.min_len; dopt.trim = o.trim;
+        dopt.min_weight = (int32_t)o.min_cov;          // main.cpp:261,279 (quirk Q1)
+        int rc = dagcon_create(&dopt, &ctx);
+        if (rc != DAGCON_OK) { fprintf(stderr, "pbdagcon: no usable MI355X (dagcon_create = %d); there is no CPU fallback\n", rc); return 1; }
+    }
+
+    // ---- parse (Alignment.cpp:44-80) and group by target id (BlasrM5AlnProvider.cpp:34-55) ----
+    Batch b;
+    std::string cur_id;
+    bool have_group = false;
+    size_t pos = 0;
+    int status = 0;
+    unsigned long long n_rec = 0;
+    while (pos < size && status == 0) {
+        const char *line = data + pos;
+        const char *nl = (const char *)memchr(line, '\n', size - pos);
+        size_t ll = nl ? (size_t)(nl - line) : size - pos;
+        pos += ll + (nl ? 1 : 0);
+        if (ll && line[ll - 1] == '\r') ll--;
+        const char *f[19];
+        size_t fl[19];
+        int nf = 0;
+        size_t i = 0;
+        while (i < ll && nf < 19) {
+            while (i < ll && line[i] == ' ') i++;
+            size_t j = i;
+            while (j < ll && line[j] != ' ') j++;
+            if (j > i) { f[nf] = line + i; fl[nf] = j - i; nf++; }
+            i = j;
+        }
+        if (nf == 0) continue;                          // blank line
+        if (nf < 19) { fprintf(stderr, "pbdagcon: format error: record %llu has %d fields, 19 expected\n", n_rec + 1, nf); status = 1; break; }
+        n_rec++;
+        if (fl[16] != fl[18]) { fprintf(stderr, "pbdagcon: format error: record %llu: query and target strings differ in length\n", n_rec); status = 1; break; }
+        const bool new_target = !have_group || cur_id.size() != fl[5] || memcmp(cur_id.data(), f[5], fl[5]) != 0;
+        if (new_target) {
+            if (have_group) b.begin.push_back(b.start.size());
+            if (b.ids.size() >= o.batch_targets || b.q.size() >= o.batch_bytes) {
+                if (o.dump) b.clear(); else status = flush(ctx, b, o);
+                if (status) break;
+            }
+            cur_id.assign(f[5], fl[5]);
+            b.ids.push_back(cur_id);
+            b.tlen.push_back(tok_u32(f[6], fl[6]));
+            have_group = true;
+        }
+        const uint32_t start = tok_u32(f[7], fl[7]) + 1;   // Alignment.cpp:65-66
+        const char strand = f[9][0];
+        b.start.push_back(start);
+        b.off.push_back(b.q.size());
+        b.len.push_back((uint32_t)fl[16]);
+        if (strand == '-') {                               // Alignment.cpp:69-75: start is NOT flipped (Q6)
+            revcomp_append(b.q, f[16], fl[16]);
+            revcomp_append(b.t, f[18], fl[18]);
+        } else {
+            b.q.append(f[16], fl[16]);
+            b.t.append(f[18], fl[18]);
+        }
+        if (o.dump) {
+            const size_t o0 = b.off.back();
+            printf("%.*s\t%u\t%u\t%c\t%.*s\t%.*s\t%.*s\n", (int)fl[5], f[5], b.tlen.back(), start, strand,
+                   (int)fl[0], f[0], (int)fl[16], b.q.data() + o0, (int)fl[18], b.t.data() + o0);
+        }
+    }
+    if (status == 0 && !o.dump) status = flush(ctx, b, o);
+    if (ctx) dagcon_destroy(ctx);
+    if (map) munmap(map, size);
+    fflush(stdout);
+    return status;
+}

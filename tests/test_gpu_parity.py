@@ -297,3 +297,32 @@ def test_idempotent_reruns_same_context(gpu_ctx_factory):
     ctx.run(); a = ctx.fetch()
     ctx.run(); b = ctx.fetch()
     assert a == b == oracle_batch(batch, 6, 500, 50)
+
+
+def test_cli_end_to_end(tmp_path):
+    """pbdagcon-compatible command line: .m5 text in, FASTA out, byte-identical to the records
+    the reference would print (main.cpp:141-143) for the oracle's segments, in input order;
+    a group below -c and a '-' strand record included; stdin ('-') gives the same bytes."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cli = os.path.join(root, "pbdagcon_amd", "bin", "pbdagcon")
+    batch = synth.make_batch(5, 1500, 12, seed=31)
+    lines = synth.to_m5(batch).decode().splitlines()
+    keep = [ln for i, ln in enumerate(lines) if not (24 <= i < 33)]      # target 2 keeps 3 < 6 alignments
+    m5 = ("\n".join(keep) + "\n").encode()
+    path = tmp_path / "in.m5"
+    path.write_bytes(m5)
+    out = subprocess.run([cli, "-c", "6", "-m", "500", "-t", "50", "-j", "1", str(path)],
+                         capture_output=True, timeout=300)
+    assert out.returncode == 0, out.stderr.decode()
+    exp = []
+    for t in range(batch.n_targets):
+        alns = [a for i, a in enumerate(batch.target_alignments(t)) if not (24 <= 12 * t + i < 33)]
+        if len(alns) < 6:
+            continue
+        for r0, r1, s in oracle.consensus_target(int(batch.tlen[t]), alns, 500, 50, 6):
+            exp.append(b">%s/%d_%d\n%s\n" % (batch.ids[t].encode(), r0, r1, s))
+    assert out.stdout == b"".join(exp) and len(exp) == 4
+    out2 = subprocess.run([cli, "-"], input=m5, capture_output=True, timeout=300)
+    assert out2.returncode == 0 and out2.stdout == out.stdout

@@ -99,3 +99,55 @@ def test_two_rank_gloo_gather(tmp_path):
         env=env, capture_output=True, text=True, timeout=240)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "GATHER_OK" in out.stdout
+
+
+def _cli():
+    path = os.path.join(ROOT, "pbdagcon_amd", "bin", "pbdagcon")
+    if not os.path.exists(path):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "pbdagcon_amd", "csrc"), "all"])
+    return path
+
+
+def test_cli_parser_matches_reference_parser(tmp_path):
+    """The C++ front end's -m 5 parser (pbdagcon --dump-parsed, no GPU involved) against the
+    oracle's parseM5, which tests/test_oracle.py pins to the reference's own Alignment.cpp:
+    '+' and '-' strands, repeated spaces, the reference's two fixture shapes."""
+    import oracle
+    from pbdagcon_amd import synth
+    oracle.build()
+    b = synth.make_batch(3, 120, 5, seed=11)
+    m5 = synth.to_m5(b).decode().splitlines()
+    # flip some records to the '-' strand (strings are stored reverse-complemented there)
+    lines = []
+    for i, ln in enumerate(m5):
+        f = ln.split(" ")
+        if i % 3 == 1:
+            f[9] = "-"
+        if i % 4 == 2:
+            f[4] = f[4] + " "            # double space: empty fields are skipped (Alignment.cpp:50-53)
+        lines.append(" ".join(f))
+    lines.insert(0, "id 3 0 3 +  ref 3 0 3 + -40645 8129 0 0 0 254 CAC |-| CGC")
+    lines.insert(1, "id 3 0 3 +  ref 3 0 3 - -40645 8129 0 0 0 254 GGCCAATT |-| AATTGGCC")
+    path = tmp_path / "in.m5"
+    path.write_text("\n".join(lines) + "\n\n")
+    out = subprocess.run([_cli(), "--dump-parsed", str(path)], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stderr
+    got = [ln.split("\t") for ln in out.stdout.splitlines()]
+    assert len(got) == len(lines)
+    for ln, g in zip(lines, got):
+        e = oracle.parse_m5(ln.encode(), True)
+        assert g == [e["id"].decode(), str(e["tlen"]), str(e["start"]), e["strand"].decode(),
+                     e["sid"].decode(), e["qstr"].decode(), e["tstr"].decode()]
+    assert got[0][5:] == ["CAC", "CGC"] and got[1][5:] == ["AATTGGCC", "GGCCAATT"]   # AlignmentTest.cpp:49-63
+
+
+def test_cli_flags_and_errors(tmp_path):
+    cli = _cli()
+    assert subprocess.run([cli], capture_output=True).returncode == 2                 # input is required
+    assert subprocess.run([cli, "-a", "x.m5"], capture_output=True).returncode == 2  # -a needs blasr_libcpp
+    assert subprocess.run([cli, "--dump-parsed", str(tmp_path / "nope.m5")], capture_output=True).returncode == 1
+    bad = tmp_path / "bad.m5"
+    bad.write_text("only three fields\n")
+    assert subprocess.run([cli, "--dump-parsed", str(bad)], capture_output=True).returncode == 1
+    v = subprocess.run([cli, "--version"], capture_output=True, text=True)
+    assert "0.3" in v.stdout
