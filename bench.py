@@ -41,7 +41,7 @@ def fasta_bytes(batch, results, id_offset=0):
     return b"".join(out)
 
 
-def cpu_baseline(batch, sample_targets, opts, cores):
+def cpu_baseline(batch, sample_targets, opts, cores, faithful=False):
     """Time the oracle on `sample_targets` targets with `cores` threads (the C
     call releases the GIL: this is the reference's N-consensus-thread layout,
     main.cpp:259-263, with one whole target per task)."""
@@ -57,7 +57,7 @@ def cpu_baseline(batch, sample_targets, opts, cores):
         segs = oracle.consensus_target_blob(
             int(batch.tlen[t]), batch.aln_start[a0:a1].copy(), batch.aln_off[a0:a1].copy(),
             batch.aln_len[a0:a1].copy(), batch.qstr, batch.tstr, opts["min_len"], opts["trim"],
-            opts["min_cov"], None)
+            opts["min_cov"], None, faithful=faithful)
         return sum(r1 - r0 for r0, r1, _ in segs)
 
     one(0)
@@ -222,6 +222,15 @@ def main():
                           f"{cores} threads, one target per task, {cdt:.1f} s wall",
             }
             line["gpu_over_cpu"] = value / v
+            # second flavour (SURVEY 8d / BASELINE.md 3): the same algorithm on the reference's kind of
+            # containers (std::map, std::list edge properties, per-vertex vectors, std::string)
+            vf, nf, fdt = cpu_baseline(batch, max(cores * 6, 32), opts, cores, faithful=True)
+            line["cpu_baseline_faithful"] = {
+                "value": vf, "unit": "bases/s", "cores": cores, "kind": "port",
+                "sample": f"first {nf} targets, oracle/cpu_faithful.cpp (reference-style containers), "
+                          f"{cores} threads, {fdt:.1f} s wall",
+            }
+            line["gpu_over_cpu_faithful"] = value / vf
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

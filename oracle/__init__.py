@@ -31,7 +31,10 @@ def build(force: bool = False) -> None:
     so = os.path.join(_HERE, "liboracle.so")
     src = os.path.join(_HERE, "dagcon_oracle.c")
     ref_so = os.path.join(_HERE, "_ref", "libref_alignment.so")
-    need = force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src)
+    cf = os.path.join(_HERE, "libcpu_faithful.so")
+    need = (force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src)
+            or not os.path.exists(cf)
+            or os.path.getmtime(cf) < os.path.getmtime(os.path.join(_HERE, "cpu_faithful.cpp")))
     need_ref = os.path.exists("/root/reference/src/cpp/Alignment.cpp") and (
         force or not os.path.exists(ref_so))
     if need or need_ref:
@@ -265,8 +268,28 @@ def consensus_target(tlen: int, alns, min_len=500, trim=50, min_weight=6, backbo
                                  min_weight, backbone)
 
 
+_CF = None
+
+
+def faithful_lib():
+    """libcpu_faithful.so: the algorithm on the reference's container classes."""
+    global _CF
+    if _CF is None:
+        so = os.path.join(_HERE, "libcpu_faithful.so")
+        if not os.path.exists(so):
+            subprocess.check_call(["make", "-s", "-C", _HERE, "libcpu_faithful.so"])
+        F = C.CDLL(so)
+        F.cf_consensus_target_blob.restype = C.c_long
+        F.cf_consensus_target_blob.argtypes = [
+            C.c_uint32, C.c_char_p, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64),
+            C.POINTER(C.c_uint32), C.c_void_p, C.c_void_p, C.POINTER(Opts),
+            C.POINTER(C.POINTER(Segment)), C.POINTER(C.c_long)]
+        _CF = F
+    return _CF
+
+
 def consensus_target_blob(tlen, starts, offs, lens, qblob, tblob, min_len=500, trim=50,
-                          min_weight=6, backbone=None):
+                          min_weight=6, backbone=None, faithful=False):
     import numpy as np
     L = lib()
     o = Opts(min_len, trim, min_weight)
@@ -274,7 +297,8 @@ def consensus_target_blob(tlen, starts, offs, lens, qblob, tblob, min_len=500, t
     bad = C.c_long(-1)
     qp = qblob.ctypes.data if isinstance(qblob, np.ndarray) else C.cast(C.c_char_p(qblob), C.c_void_p)
     tp = tblob.ctypes.data if isinstance(tblob, np.ndarray) else C.cast(C.c_char_p(tblob), C.c_void_p)
-    rc = L.og_consensus_target_blob(
+    fn = faithful_lib().cf_consensus_target_blob if faithful else L.og_consensus_target_blob
+    rc = fn(
         tlen, backbone, len(starts),
         starts.ctypes.data_as(C.POINTER(C.c_uint32)),
         offs.ctypes.data_as(C.POINTER(C.c_uint64)),

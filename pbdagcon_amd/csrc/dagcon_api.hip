@@ -194,7 +194,7 @@ int launch_all(Ctx *c) {
     HIPCHK(c, hipEventRecord(c->ev[0], s));
     if (c->A > 0) {
         hipLaunchKernelGGL(k_count, dim3(c->A), dim3(256), 0, s, p);
-        hipLaunchKernelGGL(k_normalize, dim3((c->A + 63) / 64), dim3(64), 0, s, p);
+        hipLaunchKernelGGL(k_normalize, dim3((c->A + DG_NLPW - 1) / DG_NLPW), dim3(64), 0, s, p);
         hipLaunchKernelGGL(k_normalize_slow, dim3((c->A + 63) / 64), dim3(64), 0, s, p);
     }
     HIPCHK(c, hipEventRecord(c->ev[1], s));
@@ -208,7 +208,7 @@ int launch_all(Ctx *c) {
         hipLaunchKernelGGL(k_groups, dim3(c->T, rows4), dim3(256), 0, s, p);
         hipLaunchKernelGGL(k_gscan, dim3(c->T), dim3(1024), 0, s, p);
         hipLaunchKernelGGL(k_init_nodes, dim3(c->T, (c->max_tlen + 2 + 255) / 256), dim3(256), 0, s, p);
-        if (c->A > 0) hipLaunchKernelGGL(k_emit, dim3(c->T, (c->max_k + 63) / 64), dim3(64), 0, s, p);
+        if (c->A > 0) hipLaunchKernelGGL(k_emit, dim3(c->T, (c->max_k + DG_ERPW - 1) / DG_ERPW), dim3(64), 0, s, p);
         const size_t lds = (size_t)4 * 2 * (c->max_k + 2) * sizeof(int32_t);
         if (lds > 65536)
             HIPCHK(c, hipFuncSetAttribute((const void *)k_lists, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -576,7 +576,7 @@ static int normalize_impl(Ctx *c, dagcon_ctx *ctx, uint32_t n, const uint32_t *a
         HIPCHK(c, hipMemsetAsync(c->d_st.p, 0, sizeof(DgStatus), c->stream));
         if (c->A) {
             hipLaunchKernelGGL(k_count, dim3(c->A), dim3(256), 0, c->stream, p);
-            hipLaunchKernelGGL(k_normalize, dim3((c->A + 63) / 64), dim3(64), 0, c->stream, p);
+            hipLaunchKernelGGL(k_normalize, dim3((c->A + DG_NLPW - 1) / DG_NLPW), dim3(64), 0, c->stream, p);
             hipLaunchKernelGGL(k_normalize_slow, dim3((c->A + 63) / 64), dim3(64), 0, c->stream, p);
         }
         HIPCHK(c, hipGetLastError());

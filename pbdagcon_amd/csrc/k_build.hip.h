@@ -149,9 +149,15 @@ __device__ inline void dg_finish_alignment(const DgParams &p, uint32_t a, uint16
     }
 }
 
+// alignments per wave: the kernel is bound by the latency of one lane's dependent chain, not by
+// lanes, so a wave takes DG_NLPW alignments and several waves share a SIMD
+#ifndef DG_NLPW
+#define DG_NLPW 16
+#endif
 __global__ __launch_bounds__(64) void k_normalize(DgParams p) {
-    __shared__ uint16_t s_win[64 * DG_NW_STRIDE];
-    const uint32_t a = blockIdx.x * 64 + threadIdx.x;
+    __shared__ uint16_t s_win[DG_NLPW * DG_NW_STRIDE];
+    if (threadIdx.x >= DG_NLPW) return;
+    const uint32_t a = blockIdx.x * DG_NLPW + threadIdx.x;
     if (a >= p.A) return;
     if (dg_failed(p)) return;
     const uint64_t off = p.aln_off[a];
@@ -480,6 +486,9 @@ __global__ __launch_bounds__(256) void k_init_nodes(DgParams p) {
 // the backbone ids of the batch in four 16-byte loads.
 // ---------------------------------------------------------------------------
 #define DG_EB 16
+#ifndef DG_ERPW
+#define DG_ERPW 16          // reads per wave (latency-bound: more, thinner waves overlap)
+#endif
 #define DG_ECOLS 48u          // columns staged in LDS per lane and batch (6 x 16 bytes)
 #define DG_ECOLS_STRIDE 50u   // 25 dwords per lane row: odd, lanes spread over banks
 __global__ __launch_bounds__(64) void k_emit(DgParams p) {
@@ -492,9 +501,9 @@ __global__ __launch_bounds__(64) void k_emit(DgParams p) {
     uint16_t *colw = s_col + lane * DG_ECOLS_STRIDE;
     const uint64_t ab = p.aln_begin[t];
     const uint32_t K = (uint32_t)(p.aln_begin[t + 1] - ab);
-    const uint32_t r = blockIdx.y * 64 + lane;
-    if (blockIdx.y * 64 >= K) return;
-    bool done = r >= K;
+    const uint32_t r = blockIdx.y * DG_ERPW + lane;
+    if (blockIdx.y * DG_ERPW >= K) return;
+    bool done = r >= K || lane >= DG_ERPW;         // idle lanes stay in the wave (shuffles, votes)
     const uint32_t a = (uint32_t)(ab + (done ? 0 : r));
     const uint32_t blen = p.tlen[t];
     const uint32_t exitpos = blen + 1;
@@ -630,7 +639,7 @@ __global__ __launch_bounds__(64) void k_emit(DgParams p) {
             }
         }
         // the batch leaves as row stores; rows past the exit row do not exist
-        if (r < K) {
+        if (r < K && lane < DG_ERPW) {
 #pragma unroll
             for (int j = 0; j < DG_EB; j++) {
                 const uint32_t pos = pos0 + j;

@@ -700,36 +700,59 @@ __global__ __launch_bounds__(128) void k_merge(DgParams p) {
     DG_WAVE_FENCE();
     int failed = 0;
     int prog = 0;
+    int u_next = 0;
+    bool have_next = false;
+    DgNode nu_next;                 // record of u_next, requested before the previous visit's stores
+    nu_next.out_len = 0; nu_next.in_len = 0;
 #ifdef DG_STAMPS
-    unsigned long long c_fast = 0, c_slow = 0, n_fast = 0, n_slow = 0, n_scalar = 0, t_prev = clock64(), c_a = 0, c_b = 0, c_c = 0, c_grp = 0, ng_in = 0, ng_out = 0, c_odd = 0, n_odd = 0;
+    unsigned long long c_fast = 0, c_slow = 0, n_fast = 0, n_slow = 0, n_scalar = 0, t_prev = clock64(), c_a = 0, c_b = 0, c_c = 0, c_grp = 0, ng_in = 0, ng_out = 0, c_odd = 0, n_odd = 0, q_a = 0, q_b = 0, q_c = 0, q_d = 0;
 #endif
     while (qh < qt && !failed) {
         // an entry still in the LDS ring has not been overwritten: pushes so far are < qt <= qh + DG_QRING
-        const int u = (qt - qh <= DG_QRING) ? s_ring[qh & (DG_QRING - 1)] : g.queue[qh];
+        int u;
+        const bool pre = have_next;
+        if (have_next) u = u_next;
+        else u = __builtin_amdgcn_readfirstlane((qt - qh <= DG_QRING) ? s_ring[qh & (DG_QRING - 1)] : g.queue[qh]);
+        have_next = false;
         qh++;
         bool scalar = false, merged = false;
 #ifdef DG_STAMPS
         unsigned long long ts_pre = 0, ts_in = 0, acc_grp = 0, n_grp_in = 0, n_grp_out = 0;
         const unsigned long long ts0 = clock64();
 #endif
-        if (u > prog) { prog = u; if (lane == 0) *(volatile int *)&s_prog = u; }
+        if (u > prog + 15) { prog = u; if (lane == 0) *(volatile int *)&s_prog = u; }
 
         // ---------------- the common case in one look: no merge group on either side --------
         {
-            const DgNode nu = g.nd[u];
+#ifdef DG_STAMPS
+            const unsigned long long tq0 = clock64();
+#endif
+            // gfx950 counts stores in vmcnt, so a load issued behind the previous visit's stores
+            // waits for them to reach L2: the record was requested before those stores went out
+            DgNode nu;
+            if (pre) nu = nu_next; else nu = g.nd[u];
             if (nu.in_len <= 32 && nu.out_len <= 32) {
+#ifdef DG_STAMPS
+                const unsigned long long tq1 = clock64();
+#endif
                 const bool is_in = lane < 32;
                 const int idx = lane & 31;
                 const bool valid = is_in ? idx < nu.in_len : idx < nu.out_len;
+                // one address per lane, two independent loads (an in lane's second word is not used)
+                const uint32_t ea = is_in ? nu.in_off + (uint32_t)idx : nu.out_off + 2u * (uint32_t)idx;
                 int nbr = 0, cnt = 0;
-                if (valid) {
-                    if (is_in) nbr = (int)g.pool[nu.in_off + idx];
-                    else { nbr = (int)g.pool[nu.out_off + 2 * idx]; cnt = (int)g.pool[nu.out_off + 2 * idx + 1]; }
-                }
+                if (valid) { nbr = (int)g.pool[ea]; cnt = (int)g.pool[ea + 1]; }
+#ifdef DG_STAMPS
+                asm volatile("" ::"v"(nbr), "v"(cnt));
+                const unsigned long long tq2 = clock64();
+#endif
                 uint4 h = make_uint4(0, 0, 0, 0);
                 if (valid) h = dg_lo16(&g.nd[nbr]);
                 const unsigned long long cand =
                     __ballot(valid && (is_in ? DG_H_OUTLEN(h) == 1 : DG_H_INLEN(h) == 1));
+#ifdef DG_STAMPS
+                const unsigned long long tq3 = clock64();
+#endif
                 const unsigned long long c_in = cand & 0xffffffffull;
                 unsigned long long M = 0;
                 bool in_work = false;
@@ -763,8 +786,18 @@ __global__ __launch_bounds__(128) void k_merge(DgParams p) {
                         if (!g.err) {
                             // AlnGraphBoost.cpp:143-158
                             const int pend = DG_H_PEND(h) - 1;
-                            if (live) g.nd[nbr].pending = pend;
                             const unsigned long long rm = __ballot(live && pend == 0);
+                            // the next vertex to visit is known now: the queue's head, or the first
+                            // vertex this visit enqueues
+                            if (qh < qt) {
+                                if (qt - qh <= DG_QRING) { u_next = __builtin_amdgcn_readfirstlane(s_ring[qh & (DG_QRING - 1)]); have_next = true; }
+                            } else if (rm) {
+                                u_next = DG_RL(nbr, __ffsll((long long)rm) - 1); have_next = true;
+                            }
+                            // (a vertex this visit releases still shows pending 1 in this copy; the
+                            // visit of a vertex never reads its own pending counter)
+                            if (have_next) nu_next = g.nd[u_next];
+                            if (live) g.nd[nbr].pending = pend;
                             if (live && pend == 0) {
                                 const uint32_t pos = qt + (uint32_t)__popcll(rm & DG_LT(lane));
                                 if (pos < N) { g.queue[pos] = nbr; s_ring[pos & (DG_QRING - 1)] = nbr; }
@@ -774,7 +807,7 @@ __global__ __launch_bounds__(128) void k_merge(DgParams p) {
                         }
                         failed = g.err;
 #ifdef DG_STAMPS
-                        { unsigned long long now = clock64(); if (merged) { c_slow += now - t_prev; n_slow++; } else { c_fast += now - t_prev; n_fast++; } t_prev = now; }
+                        { unsigned long long now = clock64(); if (merged) { c_slow += now - t_prev; n_slow++; } else { c_fast += now - t_prev; n_fast++; c_odd += tq0 - t_prev; q_a += tq1 - tq0; q_b += tq2 - tq1; q_c += tq3 - tq2; q_d += now - tq3; } t_prev = now; }
 #endif
                         continue;
                     }
@@ -921,6 +954,6 @@ __global__ __launch_bounds__(128) void k_merge(DgParams p) {
     }
     if (lane == 0) *(volatile int *)&s_prog = DG_PROG_DONE;
 #ifdef DG_STAMPS
-    if (t == 0 && lane == 0) { p.st->dbg[0] = n_fast; p.st->dbg[1] = n_slow; p.st->dbg[2] = c_fast; p.st->dbg[3] = c_slow; p.st->dbg[4] = n_scalar; p.st->dbg[5] = c_a; p.st->dbg[6] = c_b; p.st->dbg[7] = c_c; p.st->dbg[8] = c_grp; p.st->dbg[9] = ng_in; p.st->dbg[10] = ng_out; p.st->dbg[11] = c_odd; p.st->dbg[12] = n_odd; }
+    if (t == 0 && lane == 0) { p.st->dbg[0] = n_fast; p.st->dbg[1] = n_slow; p.st->dbg[2] = c_fast; p.st->dbg[3] = c_slow; p.st->dbg[4] = n_scalar; p.st->dbg[5] = c_a; p.st->dbg[6] = c_b; p.st->dbg[7] = c_c; p.st->dbg[8] = c_grp; p.st->dbg[9] = ng_in; p.st->dbg[10] = ng_out; p.st->dbg[11] = c_odd; p.st->dbg[12] = q_a; p.st->dbg[13] = q_b; p.st->dbg[14] = q_c; p.st->dbg[15] = q_d; }
 #endif
 }
