@@ -152,7 +152,7 @@ __device__ inline void dg_finish_alignment(const DgParams &p, uint32_t a, uint16
 // alignments per wave: the kernel is bound by the latency of one lane's dependent chain, not by
 // lanes, so a wave takes DG_NLPW alignments and several waves share a SIMD
 #ifndef DG_NLPW
-#define DG_NLPW 16
+#define DG_NLPW 64
 #endif
 __global__ __launch_bounds__(64) void k_normalize(DgParams p) {
     __shared__ uint16_t s_win[DG_NLPW * DG_NW_STRIDE];
@@ -487,7 +487,7 @@ __global__ __launch_bounds__(256) void k_init_nodes(DgParams p) {
 // ---------------------------------------------------------------------------
 #define DG_EB 16
 #ifndef DG_ERPW
-#define DG_ERPW 16          // reads per wave (latency-bound: more, thinner waves overlap)
+#define DG_ERPW 64          // reads per wave (16 or 32 were tried: no faster)
 #endif
 #define DG_ECOLS 48u          // columns staged in LDS per lane and batch (6 x 16 bytes)
 #define DG_ECOLS_STRIDE 50u   // 25 dwords per lane row: odd, lanes spread over banks
