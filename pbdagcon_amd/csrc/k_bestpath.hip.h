@@ -167,8 +167,50 @@ __global__ __launch_bounds__(64) void k_bestpath(DgParams p) {
         const int v_lo = v_hi - 63 < 0 ? 0 : v_hi - 63;
 
         for (int v = v_hi; v >= v_lo && !bad; v--) {
-            // the vertex of the stream is the bottom of the evaluation stack and stays in a
-            // register; entries above it (turned-around edges only) live in LDS, then HBM
+            // ---- straight-line step for the common case: the vertex of the stream is staged,
+            // its edges fit the slot and every successor already has its score in the ring.
+            // Two LDS trips: (lens, edges) then (successor scores). ----
+            {
+                const int xs = v & (DG_BR - 1);
+                const int el = lane < DG_BOUT ? lane : 0;
+                const int ln = __builtin_amdgcn_readfirstlane(S.lens[xs]);     // chunk c is resident: tag == v
+                const int d = S.out_dst[xs * DG_BOUT + el];
+                const float w = S.out_w[xs * DG_BOUT + el];
+                if ((ln & DG_BL_DONE) || ((ln >> 16) & DG_NF_DELETED)) continue;
+                if (!(ln & DG_BL_HBM)) {
+                    const int ol = ln & 0xffff;
+                    const int y = d & (DG_SR - 1);
+                    const int stg = S.stag[y];
+                    const float ns = w + S.sval[y];
+                    const bool ok = lane >= ol || stg == d;
+                    if (__all(ok)) {
+                        // :399-416 first maximum in list order, strict '>'
+                        float mx = 0.0f;
+                        int bd = -1;
+                        if (ol > 0) {
+                            mx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ns), 0));
+                            bd = __builtin_amdgcn_readlane(d, 0);
+                            for (int i = 1; i < ol; i++) {
+                                const float xsx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ns), i));
+                                if (xsx > mx) { mx = xsx; bd = __builtin_amdgcn_readlane(d, i); }
+                            }
+                        }
+                        if (lane == 0) {
+                            S.stag[v & (DG_SR - 1)] = v;
+                            S.sval[v & (DG_SR - 1)] = mx;
+                            S.rscore[xs] = mx; S.rbest[xs] = bd;
+                            S.lens[xs] = ln | DG_BL_DONE;
+                        }
+#ifdef DG_STAMPS
+                        n_live++;
+#endif
+                        continue;
+                    }
+                }
+            }
+            // ---- general step: the vertex of the stream is the bottom of the evaluation stack
+            // and stays in a register; entries above it (turned-around edges only) live in LDS,
+            // then HBM ----
             int sp = 1;
             while (sp > 0) {
                 int n;
