@@ -166,16 +166,25 @@ __global__ __launch_bounds__(64) void k_bestpath(DgParams p) {
         const int v_hi = N - 1 - 64 * c;
         const int v_lo = v_hi - 63 < 0 ? 0 : v_hi - 63;
 
+        // (lens, edges) of the next vertex are read one step ahead: their LDS latency overlaps
+        // the current step
+        const int el = lane < DG_BOUT ? lane : 0;
+        int pf_ln = S.lens[v_hi & (DG_BR - 1)];
+        int pf_d = S.out_dst[(v_hi & (DG_BR - 1)) * DG_BOUT + el];
+        float pf_w = S.out_w[(v_hi & (DG_BR - 1)) * DG_BOUT + el];
         for (int v = v_hi; v >= v_lo && !bad; v--) {
             // ---- straight-line step for the common case: the vertex of the stream is staged,
             // its edges fit the slot and every successor already has its score in the ring.
             // Two LDS trips: (lens, edges) then (successor scores). ----
             {
                 const int xs = v & (DG_BR - 1);
-                const int el = lane < DG_BOUT ? lane : 0;
-                const int ln = __builtin_amdgcn_readfirstlane(S.lens[xs]);     // chunk c is resident: tag == v
-                const int d = S.out_dst[xs * DG_BOUT + el];
-                const float w = S.out_w[xs * DG_BOUT + el];
+                const int ln = __builtin_amdgcn_readfirstlane(pf_ln);          // chunk c is resident: tag == v
+                const int d = pf_d;
+                const float w = pf_w;
+                if (v > v_lo) {
+                    const int xn = (v - 1) & (DG_BR - 1);
+                    pf_ln = S.lens[xn]; pf_d = S.out_dst[xn * DG_BOUT + el]; pf_w = S.out_w[xn * DG_BOUT + el];
+                }
                 if ((ln & DG_BL_DONE) || ((ln >> 16) & DG_NF_DELETED)) continue;
                 if (!(ln & DG_BL_HBM)) {
                     const int ol = ln & 0xffff;
