@@ -147,7 +147,9 @@ __global__ __launch_bounds__(64) void k_bestpath(DgParams p) {
     DG_LOAD_ENT(r_lo, r_hi);
     DG_LOAD_REC(2, n_lo, n_hi);
 
-    bool bad = false;
+    bool bad = false, stuck = false;
+    unsigned long long guard = 0;
+    const unsigned long long guard_max = 64ull * (unsigned long long)N + 1000000ull;
     // evaluation stack: the first DG_BSTK entries in LDS, the rest in the target's HBM scratch
     int32_t *gstk = p.stk + (uint64_t)t * p.stk_words;
     const int gstk_cap = (int)p.stk_words;
@@ -222,6 +224,9 @@ __global__ __launch_bounds__(64) void k_bestpath(DgParams p) {
             // then HBM ----
             int sp = 1;
             while (sp > 0) {
+                // every wave must leave this loop: the work is bounded by (vertices + edges), far
+                // below this budget; running out of it means a broken graph, not a long one
+                if (++guard > guard_max) { bad = true; stuck = true; break; }
                 int n;
                 if (sp == 1) n = v;
                 else if (sp - 2 < DG_BSTK) n = __builtin_amdgcn_readfirstlane(S.stk[sp - 2]);
@@ -264,8 +269,15 @@ __global__ __launch_bounds__(64) void k_bestpath(DgParams p) {
                     float sc = S.sval[y];
                     bool have = valid && stg == d;
                     if (valid && !have) {
-                        const float2 sg = score[d];
-                        if (sg.y == 1.0f) { have = true; sc = sg.x; }
+                        // the score ring holds the last 1024 finished ids only (a long turned-around
+                        // edge makes thousands finish early): a vertex of a resident chunk keeps its
+                        // result in its slot until the chunk's row store, everything else is in HBM
+                        const int yd = d & (DG_BR - 1);
+                        if (S.tag[yd] == d && (S.lens[yd] & DG_BL_DONE) && d >= v_lo) { have = true; sc = S.rscore[yd]; }
+                        else {
+                            const float2 sg = score[d];
+                            if (sg.y == 1.0f) { have = true; sc = sg.x; }
+                        }
                     }
                     const unsigned long long miss = __ballot(valid && !have);
                     if (miss) {
@@ -327,7 +339,10 @@ __global__ __launch_bounds__(64) void k_bestpath(DgParams p) {
 #undef DG_LOAD_REC
 #undef DG_LOAD_ENT
 #undef DG_WRITE_CHUNK
-    if (bad) { if (lane == 0) dg_fail(p, DG_E_STACK); return; }   // the host grows the scratch and re-runs
+    if (bad) {                                                    // STACK: the host grows the scratch and re-runs
+        if (lane == 0) { dg_fail(p, stuck ? DG_E_INTERNAL : DG_E_STACK); p.st->bad_target = t; }
+        return;
+    }
 #ifdef DG_STAMPS
     const unsigned long long t_sweep = clock64();
 #endif

@@ -560,7 +560,7 @@ __global__ __launch_bounds__(64) void k_emit(DgParams p) {
     uint32_t pos0 = bbpos;
     for (int o = 32; o > 0; o >>= 1) { const uint32_t x = (uint32_t)__shfl_xor((int)pos0, o); pos0 = x < pos0 ? x : pos0; }
     pos0 &= ~3u;                                   // bbv_base is a multiple of 4
-    while (!__all(done)) {
+    while (!__all(done) && pos0 <= blen + 2u * DG_EB) {   // (every read ends by position tlen + 1)
         // backbone ids of the batch: bid[pos0 .. pos0+15] (reads past tlen+1 stay inside the arena)
         uint32_t bidv[DG_EB];
         {

@@ -326,3 +326,51 @@ def test_cli_end_to_end(tmp_path):
     assert out.stdout == b"".join(exp) and len(exp) == 4
     out2 = subprocess.run([cli, "-"], input=m5, capture_output=True, timeout=300)
     assert out2.returncode == 0 and out2.stdout == out.stdout
+
+
+def test_config3_and_config5_shapes(gpu_ctx_factory):
+    """BASELINE configs[2] / configs[4] shapes from the aligned strings inward: 50 kb x 60x
+    (long target, more than 64... no: 60 reads, deep pools) and 20 kb x 30x with mixed target
+    lengths and partial spans, -t 10 as dazcon does, real backbone bases given."""
+    b3 = synth.make_batch(2, 50000, 60, seed=7000)
+    _check_batch(gpu_ctx_factory, b3, min_cov=8, min_len=500, trim=50)
+    tl = np.random.default_rng(5).integers(2000, 40000, 6)
+    b5 = synth.make_batch(6, 0, 30, seed=8000, min_span=0.6, tlens=tl, with_backbone=True)
+    _check_batch(gpu_ctx_factory, b5, min_cov=6, min_len=500, trim=10)
+
+
+def test_production_coverage_caps(gpu_ctx_factory):
+    """m4topre caps a target at 75 alignments, dazcon -m at 85: more than one
+    wave of reads per target through every kernel."""
+    b = synth.make_batch(3, 3000, 85, seed=4100)
+    _check_batch(gpu_ctx_factory, b, min_cov=8, min_len=500, trim=50)
+    b = synth.make_batch(2, 2500, 75, seed=4200, min_span=0.7)
+    _check_batch(gpu_ctx_factory, b, min_cov=8, min_len=500, trim=50)
+
+
+def test_limits_are_reported(gpu_ctx_factory):
+    """More alignments per target than DAGCON_MAX_COVERAGE is refused up front, not mis-computed."""
+    ctx = gpu_ctx_factory(min_cov=0, min_len=0, trim=0, min_weight=0)
+    n = capi.MAX_COVERAGE + 1
+    alns = [(1, b"ACGT", b"ACGT")] * n
+    with pytest.raises(capi.DagconError) as e:
+        ctx.consensus(batch_from_targets([(4, alns, b"ACGT")]))
+    assert e.value.code == -5
+
+
+def test_ragged_batch_and_workspace_growth(gpu_ctx_factory):
+    """Targets of very different sizes in one batch, on a fresh context whose first workspace
+    guess is too small for insertion-rich input: the batch is re-run with the exact sizes the
+    device recorded and the answer is the same as on a warm context."""
+    rng = np.random.default_rng(17)
+    targets = []
+    for tl, k in [(30, 3), (4000, 25), (5, 9), (900, 40), (12, 1), (2500, 12)]:
+        alns, bb = random_target(rng, tl, k, alphabet=b"ACGT", ins=0.35, dele=0.05, sub=0.02, full_span=(tl < 100))
+        targets.append((tl, alns, bb))
+    batch = batch_from_targets(targets)
+    ctx = gpu_ctx_factory(min_cov=1, min_len=0, trim=2, min_weight=1)
+    a = ctx.consensus(batch)
+    first = ctx.timings()["reruns"]
+    b = ctx.consensus(batch)
+    assert a == b == oracle_batch(batch, 1, 0, 2, 1)
+    assert ctx.timings()["reruns"] == 0 and first >= 0
