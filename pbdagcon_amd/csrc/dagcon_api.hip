@@ -51,11 +51,11 @@ struct Ctx {
     DevBuf d_node_base, d_n_nodes, d_pool_base, d_pool_size, d_pool_top, d_t_nins;
     DevBuf d_matA, d_matD, d_matC, d_cov, d_gcount, d_gbase, d_bid;
     DevBuf d_nodes, d_best, d_queue, d_score, d_cns_tmp;
-    DevBuf d_pool, d_stk;
+    DevBuf d_pool, d_stk, d_cuts;
     DevBuf d_cns, d_cns_off, d_cns_len, d_seg_first, d_n_seg, d_seg_r0, d_seg_r1, d_st;
 
     uint64_t norm_cap = 0, node_cap = 0, pool_cap = 0, cns_cap = 0, seg_cap = 0;
-    uint32_t stk_words = 16384, growth_pct = 100;
+    uint32_t stk_words = 16384, growth_pct = 100, seg_max = 8, seg_env = 0;
 
     DgStatus h_st;
     dagcon_timings tm;
@@ -130,7 +130,8 @@ int ensure_arenas(Ctx *c) {
     ENSURE(c, c->d_score, c->node_cap * 8);
     ENSURE(c, c->d_cns_tmp, c->node_cap);
     ENSURE(c, c->d_pool, c->pool_cap * 4);
-    ENSURE(c, c->d_stk, (uint64_t)c->T * c->stk_words * 4);
+    ENSURE(c, c->d_stk, (uint64_t)c->T * c->seg_max * c->stk_words * 4);
+    ENSURE(c, c->d_cuts, (uint64_t)c->T * (c->seg_max + 2) * 4);
     ENSURE(c, c->d_cns, c->cns_cap);
     ENSURE(c, c->d_seg_r0, c->seg_cap * 4);
     ENSURE(c, c->d_seg_r1, c->seg_cap * 4);
@@ -172,7 +173,10 @@ void fill_params(Ctx *c, DgParams &p) {
     p.cns_tmp = (uint8_t *)c->d_cns_tmp.p; p.node_cap = c->node_cap;
     p.pool = (uint32_t *)c->d_pool.p; p.pool_cap = c->pool_cap;
     p.stk = (int32_t *)c->d_stk.p; p.stk_words = c->stk_words; p.growth_pct = c->growth_pct;
-    { const char *e = getenv("DAGCON_PF_AHEAD"); p.pf_ahead = e ? (uint32_t)atoi(e) : 48u; }
+    // the prefetch wave pays while the chip has idle wave slots; past ~1.5 workers per SIMD the
+    // workers hide each other's latency and it only takes issue slots from them
+    { const char *e = getenv("DAGCON_PF_AHEAD"); p.pf_ahead = e ? (uint32_t)atoi(e) : ((uint64_t)c->T * c->seg_max >= 1536 ? 0u : 48u); }
+    p.seg_max = c->seg_max; p.cuts = (uint32_t *)c->d_cuts.p;
     p.cns = (uint8_t *)c->d_cns.p; p.cns_cap = c->cns_cap;
     p.cns_off = (uint64_t *)c->d_cns_off.p; p.cns_len = (uint32_t *)c->d_cns_len.p;
     p.seg_first = (uint64_t *)c->d_seg_first.p; p.n_seg = (uint32_t *)c->d_n_seg.p;
@@ -215,8 +219,11 @@ int launch_all(Ctx *c) {
         hipLaunchKernelGGL(k_lists, dim3(c->T, rows4), dim3(256), lds, s, p);
     }
     HIPCHK(c, hipEventRecord(c->ev[2], s));
-    if (c->T > 0 && !(c->opts.flags & DAGCON_FLAG_STOP_AFTER_BUILD))
-        hipLaunchKernelGGL(k_merge, dim3(c->T), dim3(128), 0, s, p);
+    if (c->T > 0 && !(c->opts.flags & DAGCON_FLAG_STOP_AFTER_BUILD)) {
+        hipLaunchKernelGGL(k_cuts, dim3(c->T), dim3(64), 0, s, p);
+        if (p.pf_ahead) hipLaunchKernelGGL(k_merge<true>, dim3(c->T * c->seg_max), dim3(128), 0, s, p);
+        else hipLaunchKernelGGL(k_merge<false>, dim3(c->T * c->seg_max), dim3(64), 0, s, p);
+    }
     HIPCHK(c, hipEventRecord(c->ev[3], s));
     if (c->T > 0 && !(c->opts.flags & (DAGCON_FLAG_STOP_AFTER_BUILD | DAGCON_FLAG_STOP_AFTER_MERGE))) {
         hipLaunchKernelGGL(k_bp_prepare, dim3(c->T, 16), dim3(256), 0, s, p);
@@ -252,6 +259,10 @@ int dagcon_create(const dagcon_opts *opts, dagcon_ctx **out) {
     Ctx *c = new Ctx();
     c->opts = *opts;
     c->device = opts->device;
+    if (const char *e = getenv("DAGCON_MERGE_SEGS")) {      // tuning knob: 1 = one worker per target
+        const int v = atoi(e);
+        if (v >= 1 && v <= 64) c->seg_env = (uint32_t)v;
+    }
     memset(&c->tm, 0, sizeof c->tm);
     memset(&c->h_st, 0, sizeof c->h_st);
     if (hipSetDevice(c->device) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess) {
@@ -276,7 +287,7 @@ void dagcon_destroy(dagcon_ctx *ctx) {
                      &c->d_n_ins, &c->d_n_del, &c->d_norm, &c->d_node_base, &c->d_n_nodes,
                      &c->d_pool_base, &c->d_pool_size, &c->d_pool_top, &c->d_t_nins, &c->d_matA, &c->d_matD,
                      &c->d_matC, &c->d_cov, &c->d_gcount, &c->d_gbase, &c->d_bid, &c->d_nodes,
-                     &c->d_best, &c->d_queue, &c->d_score, &c->d_cns_tmp, &c->d_pool, &c->d_stk, &c->d_cns,
+                     &c->d_best, &c->d_queue, &c->d_score, &c->d_cns_tmp, &c->d_pool, &c->d_stk, &c->d_cuts, &c->d_cns,
                      &c->d_cns_off, &c->d_cns_len, &c->d_seg_first, &c->d_n_seg, &c->d_seg_r0, &c->d_seg_r1,
                      &c->d_st};
     for (DevBuf *b : all) free_buf(*b);
@@ -298,6 +309,10 @@ int dagcon_upload(dagcon_ctx *ctx, const dagcon_batch *b) {
     HIPCHK(c, hipSetDevice(c->device));
 
     c->T = T;
+    // merge workers per target: about one chip's worth of resident waves (8 per SIMD x 1024
+    // SIMDs) over the batch, never fewer than 8 nor more than 32 per target
+    if (c->seg_env) c->seg_max = c->seg_env;
+    else { uint32_t sm = T ? 8192u / T : 8u; c->seg_max = sm < 8u ? 8u : sm > 32u ? 32u : sm; }
     c->h_tlen.assign(b->tlen, b->tlen + T);
     c->h_aln_begin.assign(T + 1, 0);
     c->h_tactive.assign(T, 0);

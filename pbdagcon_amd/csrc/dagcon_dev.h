@@ -122,6 +122,8 @@ struct DgParams {
     uint32_t stk_words;
     uint32_t growth_pct;           // pool growth region as % of the initial adjacency words
     uint32_t pf_ahead;             // vertices the prefetch wave runs ahead of the sweep (0 = off)
+    uint32_t seg_max;              // most segments a target's merge sweep is split into (k_cuts)
+    uint32_t *cuts;                // [T][seg_max + 2]: segment count, first vertex of each segment
     // ---- outputs ----
     uint8_t *cns;
     uint64_t cns_cap;

@@ -85,9 +85,8 @@ __device__ inline void dgg_in_erase(DgGraph &g, int v, int idx) {
     g.nd[v].in_len = (uint16_t)(n - 1);
 }
 __device__ inline uint32_t dgg_alloc(DgGraph &g, uint32_t words) {
-    const uint32_t off = *g.pool_top;
+    const uint32_t off = atomicAdd(g.pool_top, words);   // shared by the segment workers of the target
     if ((uint64_t)off + words > g.pool_size) { dgg_fail(g, DG_E_POOL_TGT); return 0xFFFFFFFFu; }
-    *g.pool_top = off + words;
     return off;
 }
 __device__ inline void dgg_out_append(DgGraph &g, int v, int dst, int count) {
@@ -323,22 +322,22 @@ __device__ inline void dgg_merge_out(DgGraph &g, int n) {
 #define DG_PF_CHUNK 64
 
 __device__ inline void dg_prefetch_wave(const DgNode *nd, const uint32_t *pool, uint32_t pool_size,
-                                        int N, volatile int *s_prog, int lane, int dir, int ahead) {
+                                        int lo, int N, int *s_prog, int lane, int dir, int ahead) {
     if (ahead <= 0) return;
-    int next = dir > 0 ? 0 : N - 1;
+    int next = dir > 0 ? lo : N - 1;
     unsigned spins = 0;
     uint32_t sink = 0;
     for (;;) {
-        const int cur = *s_prog;
+        const int cur = __hip_atomic_load(s_prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (cur == DG_PROG_DONE) break;
-        const bool work = dir > 0 ? (next < N && next < cur + ahead) : (next >= 0 && next > cur - ahead);
+        const bool work = dir > 0 ? (next < N && next < cur + ahead) : (next >= lo && next > cur - ahead);
         if (!work) {
-            if ((dir > 0 ? next >= N : next < 0) || ++spins > 400000000u) break;
+            if ((dir > 0 ? next >= N : next < lo) || ++spins > 400000000u) break;
             __builtin_amdgcn_s_sleep(4);
             continue;
         }
         const int v = next + dir * lane;
-        if (v >= 0 && v < N) {
+        if (v >= lo && v < N) {
             const uint4 h2 = *(reinterpret_cast<const uint4 *>(&nd[v]) + 1);
             if (h2.x < pool_size) sink ^= pool[h2.x];
             if (h2.y < pool_size) sink ^= pool[h2.y];
@@ -416,10 +415,10 @@ __device__ __forceinline__ uint32_t dg_wave_alloc(DgGraph &g, uint32_t words, in
     return off;
 }
 
-// Removes from in[v] every source listed in vic[0..k) (stable), then appends
-// `app` when app >= 0.  pend_delta is added to v's pending counter.
+// Removes from in[v] every source held (in `vid`) by a lane of vm (stable), then
+// appends `app` when app >= 0.  pend_delta is added to v's pending counter.
 // Requires in_len(v) <= 64.
-__device__ inline void dgw_in_rewrite(DgGraph &g, int v, const volatile int *vic, int k, int app,
+__device__ inline void dgw_in_rewrite(DgGraph &g, int v, int vid, unsigned long long vm, int app,
                                       int pend_delta, int lane) {
     const uint4 h = dg_lo16(&g.nd[v]), h2 = dg_hi16(&g.nd[v]);
     const int len = DG_H_INLEN(h);
@@ -428,7 +427,7 @@ __device__ inline void dgw_in_rewrite(DgGraph &g, int v, const volatile int *vic
     int e = -1;
     if (lane < len) e = (int)g.pool[off + lane];
     bool rm = false;
-    for (int q = 0; q < k; q++) rm |= (e == vic[q]);
+    for (unsigned long long m = vm; m; m &= m - 1ull) rm |= (e == DG_RL(vid, __ffsll((long long)m) - 1));
     const bool keep = lane < len && !rm;
     const unsigned long long km = __ballot(keep);
     int nlen = __popcll(km);
@@ -454,12 +453,10 @@ __device__ inline void dgw_in_rewrite(DgGraph &g, int v, const volatile int *vic
 // target's record).  M = lanes of the group (survivor = lowest lane).
 // Returns false, with nothing modified, when a list involved is longer than a wave.
 __device__ inline bool dgw_merge_out_group(DgGraph &g, int u, const DgNode &nu, unsigned long long M,
-                                           int d, int &cnt, uint4 h, bool valid_out, int lane,
-                                           volatile int *s_vic) {
+                                           int d, int &cnt, uint4 h, bool valid_out, int lane) {
     const int an_lane = __ffsll((long long)M) - 1;
     const unsigned long long vm = M & ~(1ull << an_lane);
     const int an = DG_RL(d, an_lane);
-    const int k = __popcll(vm);
     const bool member = (M >> lane) & 1ull;
     uint4 h2 = make_uint4(0, 0, 0, 0);
     if (member) h2 = dg_hi16(&g.nd[d]);
@@ -487,7 +484,6 @@ __device__ inline bool dgw_merge_out_group(DgGraph &g, int u, const DgNode &nu, 
     if (__ballot(vic_entry && DG_H_INLEN(hn2) > 64)) return false;
 
     // ---- nothing has been modified up to here ----
-    if (vm >> lane & 1ull) s_vic[__popcll(vm & DG_LT(lane))] = d;
     // :236-243 count(u->an) += counts of u->victims, weight[an] += weights
     const int add_cnt = dg_wave_sum_masked(cnt, vm);
     const int add_w = dg_wave_sum_masked(DG_H_WEIGHT(h), vm);
@@ -506,7 +502,7 @@ __device__ inline bool dgw_merge_out_group(DgGraph &g, int u, const DgNode &nu, 
         const int nv = __popcll(vsame);
         if (nv) {
             const bool is_new = (vsame >> f) & 1ull;       // survivor had no edge to x
-            dgw_in_rewrite(g, x, s_vic, k, is_new ? an : -1, -(nv - (is_new ? 1 : 0)), lane);
+            dgw_in_rewrite(g, x, d, vm, is_new ? an : -1, -(nv - (is_new ? 1 : 0)), lane);
             if (g.err) return true;
         }
     }
@@ -559,13 +555,11 @@ __device__ inline bool dgw_merge_out_group(DgGraph &g, int u, const DgNode &nu, 
 // M = lanes of the group (survivor = lowest lane).  *an_out = survivor.
 // Returns false, with nothing modified, when a list involved is longer than a wave.
 __device__ inline bool dgw_merge_in_group(DgGraph &g, int n, const DgNode &nn, unsigned long long M,
-                                          int s, uint4 h, bool valid_in, int lane,
-                                          volatile int *s_vic, int *an_out) {
+                                          int s, uint4 h, bool valid_in, int lane, int *an_out) {
     const int an_lane = __ffsll((long long)M) - 1;
     const unsigned long long vm = M & ~(1ull << an_lane);
     const int an = DG_RL(s, an_lane);
     *an_out = an;
-    const int k = __popcll(vm);
     const bool member = (M >> lane) & 1ull;
     const bool victim = (vm >> lane) & 1ull;
     uint4 h2 = make_uint4(0, 0, 0, 0);
@@ -595,7 +589,6 @@ __device__ inline bool dgw_merge_in_group(DgGraph &g, int n, const DgNode &nn, u
     if (__ballot(fl && DG_H_OUTLEN(hn1) > 64)) return false;
 
     // ---- nothing has been modified up to here ----
-    if (victim) s_vic[__popcll(vm & DG_LT(lane))] = s;
     // :183-190 survivor's out edge count and weight
     const int add_cnt = dg_wave_sum_masked(c0, vm);
     const int add_w = dg_wave_sum_masked(DG_H_WEIGHT(h), vm);
@@ -620,7 +613,7 @@ __device__ inline bool dgw_merge_in_group(DgGraph &g, int n, const DgNode &nn, u
         int dst = -1, c = 0;
         if (lane < xlen) { dst = (int)g.pool[xoff + 2 * lane]; c = (int)g.pool[xoff + 2 * lane + 1]; }
         bool isv = false;
-        for (int q = 0; q < k; q++) isv |= (dst == s_vic[q]);
+        for (unsigned long long m = vm; m; m &= m - 1ull) isv |= (dst == DG_RL(s, __ffsll((long long)m) - 1));
         const unsigned long long vmask = __ballot(lane < xlen && isv);
         const int csum = dg_wave_sum_masked(c, vmask);
         const unsigned long long apos = __ballot(lane < xlen && dst == an);
@@ -670,36 +663,104 @@ __device__ inline bool dgw_merge_in_group(DgGraph &g, int n, const DgNode &nn, u
     return true;
 }
 
-// ---- mergeNodes (AlnGraphBoost.cpp:129-160): one wave per target ------------
+// ---- cut vertices: where the sweep of a target can be split exactly -----------
+// A backbone vertex v that EVERY read of the target passes through (weight - 1 ==
+// reads threaded into the graph) is a cut of the alignment graph: vertex ids rise
+// along every edge addAln creates (k_emit numbers the vertices in backbone order),
+// so no edge jumps over v, every vertex before v is an ancestor of v and every
+// vertex after it a descendant, and merging (which only unifies vertices of one
+// side: v can never be a member of a merge group, that would close a cycle)
+// keeps it so.  The reference's FIFO therefore holds exactly {v} when v is
+// dequeued: everything before v is finished, nothing after v has started, and
+// the two sides touch disjoint state (of v itself: the in list and pending
+// counter belong to the side before, the out list to the side after).  The
+// segments between consecutive cuts are swept concurrently, each in exactly the
+// reference's order: a segment starts with the visit of its cut vertex minus
+// mergeInNodes (the previous segment's worker does that as its last act) and
+// ends when it dequeues the next cut vertex.
+// row of p.cuts: [0] = number of segments, [1 + s] = first vertex of segment s.
+#define DG_SEG_MIN 768u          // shortest backbone stretch worth a worker of its own
+__global__ __launch_bounds__(64) void k_cuts(DgParams p) {
+    const uint32_t t = blockIdx.x;
+    if (dg_failed(p) || !p.tactive[t]) return;
+    const int lane = threadIdx.x;
+    uint32_t *row = p.cuts + (uint64_t)t * (p.seg_max + 2u);
+    const uint32_t blen = p.tlen[t];
+    const DgNode *nd = p.nodes + p.node_base[t];
+    const uint32_t *pool = p.pool + p.pool_base[t];
+    const uint32_t *bid = p.bid + p.bbv_base[t];
+    // reads threaded into the graph = uses of enter's out-edges (AlnGraphBoost.cpp:60,106)
+    const DgNode en = nd[0];
+    int kg = 0;
+    for (int i = lane; i < en.out_len; i += 64) kg += (int)pool[en.out_off + 2 * i + 1];
+    for (int o = 32; o; o >>= 1) kg += __shfl_xor(kg, o);
+    uint32_t want = blen / DG_SEG_MIN;
+    if (want > p.seg_max) want = p.seg_max;
+    if (want < 1) want = 1;
+    uint32_t nseg = 1;
+    if (lane == 0) row[1] = 0;
+    for (uint32_t s = 1; s < want; s++) {
+        const uint32_t p0 = 1u + (uint32_t)((uint64_t)s * blen / want);
+        const uint32_t span = blen / want / 2u;          // stays below the next ideal position
+        uint32_t found = 0;
+        for (uint32_t o = 0; o < span && !found; o += 64) {
+            const uint32_t pos = p0 + o + (uint32_t)lane;
+            uint32_t v = 0;
+            bool ok = false;
+            if (o + (uint32_t)lane < span && pos >= 1 && pos <= blen) {
+                v = bid[pos];
+                ok = nd[v].weight - 1 == kg;
+            }
+            const unsigned long long m = __ballot(ok);
+            if (m) found = (uint32_t)DG_RL(v, __ffsll((long long)m) - 1);
+        }
+        if (found) { if (lane == 0) row[1 + nseg] = found; nseg++; }
+    }
+    if (lane == 0) row[0] = nseg;
+}
+
+// ---- mergeNodes (AlnGraphBoost.cpp:129-160): one wave per (target, segment) ----
 #define DG_IN_STACK 48
 #define DG_QRING 256
 
-__global__ __launch_bounds__(128) void k_merge(DgParams p) {
-    const uint32_t t = blockIdx.x;
+// PF: a second wave runs ahead of the worker and pulls the records and lists it is about to
+// need into L2 (pays when the chip has idle wave slots: few targets x segments in flight)
+#define DG_PROG_SET(x) __hip_atomic_store(&s_prog, (x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+template <bool PF>
+__global__ __launch_bounds__(PF ? 128 : 64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_merge(DgParams p) {
+    const uint32_t t = blockIdx.x / p.seg_max, seg = blockIdx.x % p.seg_max;
     if (dg_failed(p) || !p.tactive[t]) return;
+    const uint32_t *crow = p.cuts + (uint64_t)t * (p.seg_max + 2u);
+    const uint32_t nseg = crow[0];
+    if (seg >= nseg) return;
     const int lane = threadIdx.x & 63;
     const uint64_t nb = p.node_base[t];
+    const uint32_t NT = p.n_nodes[t];
+    const int c_start = (int)crow[1 + seg];
+    const int c_end = seg + 1 < nseg ? (int)crow[2 + seg] : 0x7fffffff;     // the next segment's cut vertex
+    const int c_hi = seg + 1 < nseg ? c_end : (int)NT - 1;
     __shared__ int s_prog;
-    if (threadIdx.x == 0) s_prog = 0;
-    __syncthreads();
-    if (threadIdx.x >= 64) {                             // wave 1: prefetcher
-        dg_prefetch_wave(p.nodes + nb, p.pool + p.pool_base[t], p.pool_size[t], (int)p.n_nodes[t], &s_prog, lane, +1, (int)p.pf_ahead);
+    if (PF) {
+        if (threadIdx.x == 0) s_prog = c_start;
+        __syncthreads();
+    }
+    if (PF && threadIdx.x >= 64) {                       // wave 1: prefetcher
+        dg_prefetch_wave(p.nodes + nb, p.pool + p.pool_base[t], p.pool_size[t], c_start, c_hi + 1, &s_prog, lane, +1, (int)p.pf_ahead);
         return;
     }
     DgGraph g;
-    g.nd = p.nodes + nb; g.queue = p.queue + nb;
+    g.nd = p.nodes + nb; g.queue = p.queue + nb + c_start;          // the segment's own stretch of the queue
     g.pool = p.pool + p.pool_base[t]; g.pool_size = p.pool_size[t]; g.pool_top = p.pool_top + t;
-    g.stk = p.stk + (uint64_t)t * p.stk_words; g.stk_words = p.stk_words;
+    g.stk = p.stk + (uint64_t)blockIdx.x * p.stk_words; g.stk_words = p.stk_words;
     g.st = p.st; g.t = t; g.err = false;
-    const uint32_t N = p.n_nodes[t];
-    __shared__ int s_vic[64];
+    const uint32_t N = (uint32_t)(c_hi - c_start + 1);               // vertices this worker can dequeue
     __shared__ int s_stk[2 * DG_IN_STACK];
     __shared__ int s_ring[DG_QRING];                     // the youngest DG_QRING queue entries
     uint32_t qh = 0, qt = 1;
-    if (lane == 0) { g.queue[0] = 0; s_ring[0] = 0; }    // enter vertex
+    if (lane == 0) { g.queue[0] = c_start; s_ring[0] = c_start; }    // enter vertex / cut vertex
     DG_WAVE_FENCE();
     int failed = 0;
-    int prog = 0;
+    int prog = c_start;
     int u_next = 0;
     bool have_next = false;
     DgNode nu_next;                 // record of u_next, requested before the previous visit's stores
@@ -712,7 +773,8 @@ __global__ __launch_bounds__(128) void k_merge(DgParams p) {
         int u;
         const bool pre = have_next;
         if (have_next) u = u_next;
-        else u = __builtin_amdgcn_readfirstlane((qt - qh <= DG_QRING) ? s_ring[qh & (DG_QRING - 1)] : g.queue[qh]);
+        else if (qt - qh <= DG_QRING) u = __builtin_amdgcn_readfirstlane(s_ring[qh & (DG_QRING - 1)]);
+        else u = __builtin_amdgcn_readfirstlane(g.queue[qh]);
         have_next = false;
         qh++;
         bool scalar = false, merged = false;
@@ -720,7 +782,14 @@ __global__ __launch_bounds__(128) void k_merge(DgParams p) {
         unsigned long long ts_pre = 0, ts_in = 0, acc_grp = 0, n_grp_in = 0, n_grp_out = 0;
         const unsigned long long ts0 = clock64();
 #endif
-        if (u > prog + 15) { prog = u; if (lane == 0) *(volatile int *)&s_prog = u; }
+        if (PF && u > prog + 15) { prog = u; if (lane == 0) DG_PROG_SET(u); }
+        if (u < c_start || u > c_hi) {                    // cannot happen (see k_cuts): refuse rather than race
+            if (lane == 0) dgg_fail(g, DG_E_INTERNAL);
+            break;
+        }
+        const bool skip_in = seg > 0 && u == c_start;     // the previous segment's worker merges in[u]
+        const bool in_only = u == c_end;                  // ... which is this, for the next segment
+        if (in_only && qh != qt) { if (lane == 0) dgg_fail(g, DG_E_INTERNAL); break; }
 
         // ---------------- the common case in one look: no merge group on either side --------
         {
@@ -731,13 +800,14 @@ __global__ __launch_bounds__(128) void k_merge(DgParams p) {
             // waits for them to reach L2: the record was requested before those stores went out
             DgNode nu;
             if (pre) nu = nu_next; else nu = g.nd[u];
-            if (nu.in_len <= 32 && nu.out_len <= 32) {
+            const int eff_in = skip_in ? 0 : (int)nu.in_len, eff_out = in_only ? 0 : (int)nu.out_len;
+            if (eff_in <= 32 && eff_out <= 32) {
 #ifdef DG_STAMPS
                 const unsigned long long tq1 = clock64();
 #endif
                 const bool is_in = lane < 32;
                 const int idx = lane & 31;
-                const bool valid = is_in ? idx < nu.in_len : idx < nu.out_len;
+                const bool valid = is_in ? idx < eff_in : idx < eff_out;
                 // one address per lane, two independent loads (an in lane's second word is not used)
                 const uint32_t ea = is_in ? nu.in_off + (uint32_t)idx : nu.out_off + 2u * (uint32_t)idx;
                 int nbr = 0, cnt = 0;
@@ -757,6 +827,7 @@ __global__ __launch_bounds__(128) void k_merge(DgParams p) {
                 unsigned long long M = 0;
                 bool in_work = false;
                 if (__popcll(c_in) >= 2) in_work = dg_pick_group(c_in, DG_H_BASE(h), -1, lane, &M) != 256;
+                if (!in_work && in_only) break;           // nothing to merge in front of the cut: segment done
                 if (!in_work) {
                     // mergeOutNodes(u) on the resident out entries (lanes 32..63), group by group
                     bool live = valid && !is_in;
@@ -770,7 +841,7 @@ __global__ __launch_bounds__(128) void k_merge(DgParams p) {
 #ifdef DG_STAMPS
                         const unsigned long long tg0 = clock64();
 #endif
-                        const bool okg = dgw_merge_out_group(g, u, nu, M, nbr, cnt, h, live, lane, s_vic);
+                        const bool okg = dgw_merge_out_group(g, u, nu, M, nbr, cnt, h, live, lane);
 #ifdef DG_STAMPS
                         c_grp += clock64() - tg0; ng_out++;
 #endif
@@ -821,7 +892,7 @@ __global__ __launch_bounds__(128) void k_merge(DgParams p) {
         ts_pre = clock64();
 #endif
         // ---------------- mergeInNodes(u), recursion on an explicit stack ----------------
-        int sp = 1;
+        int sp = skip_in ? 0 : 1;
         int fr_n = u, fr_last = -1;                       // top frame lives in registers
         while (sp > 0) {
             const DgNode nn = g.nd[fr_n];
@@ -845,7 +916,7 @@ __global__ __launch_bounds__(128) void k_merge(DgParams p) {
 #ifdef DG_STAMPS
             const unsigned long long tg0 = clock64();
 #endif
-            if (!dgw_merge_in_group(g, fr_n, nn, M, s, h, valid, lane, s_vic, &an)) { scalar = true; break; }
+            if (!dgw_merge_in_group(g, fr_n, nn, M, s, h, valid, lane, &an)) { scalar = true; break; }
 #ifdef DG_STAMPS
             acc_grp += clock64() - tg0; n_grp_in++;
 #endif
@@ -870,6 +941,7 @@ __global__ __launch_bounds__(128) void k_merge(DgParams p) {
 #ifdef DG_STAMPS
         ts_in = clock64();
 #endif
+        if (in_only) break;                               // the next segment's worker does the rest of this visit
         // ---------------- mergeOutNodes(u) + FIFO bookkeeping ----------------
         bool done = false;
         if (scalar) {
@@ -895,11 +967,11 @@ __global__ __launch_bounds__(128) void k_merge(DgParams p) {
                 if (b != 256) {
 #ifdef DG_STAMPS
                     const unsigned long long tg0 = clock64();
-                    const bool okg = dgw_merge_out_group(g, u, nu, M, d, cnt, h, valid, lane, s_vic);
+                    const bool okg = dgw_merge_out_group(g, u, nu, M, d, cnt, h, valid, lane);
                     acc_grp += clock64() - tg0; n_grp_out++;
                     if (okg) {
 #else
-                    if (dgw_merge_out_group(g, u, nu, M, d, cnt, h, valid, lane, s_vic)) {
+                    if (dgw_merge_out_group(g, u, nu, M, d, cnt, h, valid, lane)) {
 #endif
                         merged = true;
                         last_out = b;
@@ -952,8 +1024,8 @@ __global__ __launch_bounds__(128) void k_merge(DgParams p) {
         { unsigned long long now = clock64(); if (merged || scalar) { c_slow += now - t_prev; n_slow++; n_scalar += scalar; c_a += ts_pre - ts0; c_b += ts_in - ts_pre; c_c += now - ts_in; c_grp += acc_grp; ng_in += n_grp_in; ng_out += n_grp_out; } else { c_fast += now - t_prev; n_fast++; c_odd += now - t_prev; n_odd++; } t_prev = now; }
 #endif
     }
-    if (lane == 0) *(volatile int *)&s_prog = DG_PROG_DONE;
+    if (PF && lane == 0) DG_PROG_SET(DG_PROG_DONE);
 #ifdef DG_STAMPS
-    if (t == 0 && lane == 0) { p.st->dbg[0] = n_fast; p.st->dbg[1] = n_slow; p.st->dbg[2] = c_fast; p.st->dbg[3] = c_slow; p.st->dbg[4] = n_scalar; p.st->dbg[5] = c_a; p.st->dbg[6] = c_b; p.st->dbg[7] = c_c; p.st->dbg[8] = c_grp; p.st->dbg[9] = ng_in; p.st->dbg[10] = ng_out; p.st->dbg[11] = c_odd; p.st->dbg[12] = q_a; p.st->dbg[13] = q_b; p.st->dbg[14] = q_c; p.st->dbg[15] = q_d; }
+    if (t == 0 && seg == 0 && lane == 0) { p.st->dbg[0] = n_fast; p.st->dbg[1] = n_slow; p.st->dbg[2] = c_fast; p.st->dbg[3] = c_slow; p.st->dbg[4] = n_scalar; p.st->dbg[5] = c_a; p.st->dbg[6] = c_b; p.st->dbg[7] = c_c; p.st->dbg[8] = c_grp; p.st->dbg[9] = ng_in; p.st->dbg[10] = ng_out; p.st->dbg[11] = c_odd; p.st->dbg[12] = q_a; p.st->dbg[13] = q_b; p.st->dbg[14] = q_c; p.st->dbg[15] = q_d; }
 #endif
 }
