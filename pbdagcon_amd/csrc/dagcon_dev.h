@@ -124,6 +124,7 @@ struct DgParams {
     uint32_t pf_ahead;             // vertices the prefetch wave runs ahead of the sweep (0 = off)
     uint32_t seg_max;              // most segments a target's merge sweep is split into (k_cuts)
     uint32_t *cuts;                // [T][seg_max + 2]: segment count, first vertex of each segment
+    float *bp_stat;                // [T][seg_max][2]: largest |score| of the segment, score of its first vertex
     // ---- outputs ----
     uint8_t *cns;
     uint64_t cns_cap;

@@ -13,7 +13,8 @@
 //
 //   k_bp_prepare  thread per vertex, whole chip: w(e) for every out edge, written over the
 //                 edge count in the out list (the counts are not needed any more).
-//   k_bestpath    one wave per target; what is left is the bare recurrence.  Vertex ids
+//   k_bp_sweep    one wave per (target, segment between two cut vertices of k_cuts); what
+//                 is left is the bare recurrence.  Vertex ids
 //                 are in backbone-position order, a topological order except for the few
 //                 edges the merge turned around.  The wave STREAMS the vertices from the
 //                 exit downwards: the records of 64 vertices at a time are requested two
@@ -24,8 +25,9 @@
 //                 An edge to a vertex that has no score yet (a turned-around edge) puts
 //                 that vertex on a small stack and it is scored first.  Whatever is not
 //                 in the rings (long lists, far-away successors) comes from HBM.
-//                 The best-edge walk (:443-456) and the segmentation (:327-373) follow,
-//                 on LDS-staged (best, base, weight) triples.
+//   k_bp_walk     one wave per target: checks that the segmented sweep was exact (else
+//                 sweeps the target in one piece), then the best-edge walk (:443-456) and
+//                 the segmentation (:327-373) on LDS-staged (best, base, weight) triples.
 //
 // fp32 throughout; every value is a multiple of 0.5 below 2^23, so the arithmetic is
 // exact (-ffp-contract=off).
@@ -61,8 +63,12 @@ __global__ __launch_bounds__(256) void k_bp_prepare(DgParams p) {
     }
 }
 
-#define DG_BR 256            // staged vertices (id & 255)
-#define DG_SR 1024           // finished scores (id & 1023)
+// LDS per sweep wave is what bounds the waves in flight (8 segments x 1000 targets want
+// ~8 KB each): only the chunk being swept needs its edges staged, and successors are
+// almost always within a few hundred ids
+#define DG_BR 64             // staged vertices (id & 63): the chunk being swept
+#define DG_SR 256            // finished scores (id & 255)
+#define DG_WR 256            // the walk's staging ring
 #define DG_BOUT 6            // out edges kept in a staged slot
 #define DG_BSTK 64           // vertices waiting for a successor's score
 #define DG_BL_HBM  0x40000000  // lens: the edges did not fit the slot
@@ -78,36 +84,33 @@ struct DgBpShared {
     int stk[DG_BSTK];
     int rbest[DG_BR];
     float rscore[DG_BR];                 // results of the chunk being swept, flushed at its end
+};
+struct DgWalkShared {
     unsigned char wbuf[64];              // consensus bases of the walk, flushed 64 at a time
-    int wtag[DG_BR], wbest[DG_BR], wbase[DG_BR], wweight[DG_BR];   // the walk's staging ring
+    int wtag[DG_WR], wbest[DG_WR], wbase[DG_WR], wweight[DG_WR];   // the walk's staging ring
 };
 
-__global__ __launch_bounds__(64) void k_bestpath(DgParams p) {
-    const uint32_t t = blockIdx.x;
-    if (dg_failed(p) || !p.tactive[t]) return;
-    const int lane = threadIdx.x;
-    const uint64_t nb = p.node_base[t];
-    __shared__ DgBpShared S;
-    __shared__ uint32_t s_len, s_nseg;
-    const DgNode *nd = p.nodes + nb;
-    int32_t *best = p.best + nb;
-    float2 *score = p.score + nb;
-    const uint32_t *pool = p.pool + p.pool_base[t];
-    const int N = (int)p.n_nodes[t];
-    const int exitv = N - 1;
-
+// Scores the vertices v_top .. v_bot (descending ids) of one target.  c_top >= 0: the
+// vertex every path of this stretch ends in (the next cut, see k_cuts); it counts as
+// score 0 and is not evaluated, so the scores are relative to it.  amax = largest
+// |score| seen.
+__device__ __forceinline__ void dg_bp_sweep(DgBpShared &S, const DgNode *nd, int32_t *best, float2 *score,
+                                            const uint32_t *pool, const int v_top, const int v_bot,
+                                            const int c_top, int32_t *gstk, const int gstk_cap,
+                                            const int lane, float &amax, bool &bad, bool &stuck) {
     for (int i = lane; i < DG_SR; i += 64) S.stag[i] = -1;
-    for (int i = lane; i < DG_BR; i += 64) { S.tag[i] = -1; S.wtag[i] = -1; }
+    for (int i = lane; i < DG_BR; i += 64) S.tag[i] = -1;
+    if (c_top >= 0 && lane == 0) { S.stag[c_top & (DG_SR - 1)] = c_top; S.sval[c_top & (DG_SR - 1)] = 0.0f; }
 
     // ---- staging registers: r_* = records of a chunk, e_* = its edges ----
     uint4 r_lo, r_hi, n_lo, n_hi;
     int e_dst[DG_BOUT], e_w[DG_BOUT];
-    // chunk c holds ids [N-1-64c-63, N-1-64c]; lane l -> id N-1-64c-l
+    // chunk c holds ids [v_top-64c-63, v_top-64c]; lane l -> id v_top-64c-l
 #define DG_LOAD_REC(C, LO, HI)                                                             \
     do {                                                                                    \
-        const int v_ = N - 1 - 64 * (C) - lane;                                             \
+        const int v_ = v_top - 64 * (C) - lane;                                             \
         LO = make_uint4(0, 0, 0, 0); HI = make_uint4(0, 0, 0, 0);                           \
-        if (v_ >= 0) {                                                                      \
+        if (v_ >= v_bot) {                                                                      \
             LO = *reinterpret_cast<const uint4 *>(&nd[v_]);                                 \
             HI = *(reinterpret_cast<const uint4 *>(&nd[v_]) + 1);                           \
         }                                                                                   \
@@ -122,8 +125,8 @@ __global__ __launch_bounds__(64) void k_bestpath(DgParams p) {
     } while (0)
 #define DG_WRITE_CHUNK(C, LO)                                                               \
     do {                                                                                    \
-        const int v_ = N - 1 - 64 * (C) - lane;                                             \
-        if (v_ >= 0) {                                                                      \
+        const int v_ = v_top - 64 * (C) - lane;                                             \
+        if (v_ >= v_bot) {                                                                      \
             const int x_ = v_ & (DG_BR - 1);                                                \
             const int ol_ = (int)((LO).x & 0xffffu);                                        \
             int ln_ = (ol_ <= DG_BOUT ? ol_ : DG_BL_HBM) | (int)(((LO).y >> 8) & 0xffu) << 16; \
@@ -138,7 +141,7 @@ __global__ __launch_bounds__(64) void k_bestpath(DgParams p) {
         }                                                                                   \
     } while (0)
 
-    const int n_chunks = (N + 63) / 64;
+    const int n_chunks = (v_top - v_bot + 1 + 63) / 64;
     // prologue: chunk 0 into the ring; chunk 1 records + edges, chunk 2 records in flight
     DG_LOAD_REC(0, r_lo, r_hi);
     DG_LOAD_ENT(r_lo, r_hi);
@@ -147,16 +150,8 @@ __global__ __launch_bounds__(64) void k_bestpath(DgParams p) {
     DG_LOAD_ENT(r_lo, r_hi);
     DG_LOAD_REC(2, n_lo, n_hi);
 
-    bool bad = false, stuck = false;
     unsigned long long guard = 0;
-    const unsigned long long guard_max = 64ull * (unsigned long long)N + 1000000ull;
-    // evaluation stack: the first DG_BSTK entries in LDS, the rest in the target's HBM scratch
-    int32_t *gstk = p.stk + (uint64_t)t * p.stk_words;
-    const int gstk_cap = (int)p.stk_words;
-#ifdef DG_STAMPS
-    unsigned long long n_live = 0, n_stack = 0, n_hbm = 0;
-    const unsigned long long t_begin = clock64();
-#endif
+    const unsigned long long guard_max = 64ull * (unsigned long long)(v_top - v_bot + 1) + 1000000ull;
     for (int c = 0; c < n_chunks && !bad; c++) {
         if (c > 0) {
             // chunk c: its records and edges were requested a whole chunk ago
@@ -165,8 +160,8 @@ __global__ __launch_bounds__(64) void k_bestpath(DgParams p) {
             DG_LOAD_ENT(r_lo, r_hi);                       // chunk c+1
             DG_LOAD_REC(c + 2, n_lo, n_hi);                // chunk c+2
         }
-        const int v_hi = N - 1 - 64 * c;
-        const int v_lo = v_hi - 63 < 0 ? 0 : v_hi - 63;
+        const int v_hi = v_top - 64 * c;
+        const int v_lo = v_hi - 63 < v_bot ? v_bot : v_hi - 63;
 
         // (lens, edges) of the next vertex are read one step ahead: their LDS latency overlaps
         // the current step
@@ -212,9 +207,7 @@ __global__ __launch_bounds__(64) void k_bestpath(DgParams p) {
                             S.rscore[xs] = mx; S.rbest[xs] = bd;
                             S.lens[xs] = ln | DG_BL_DONE;
                         }
-#ifdef DG_STAMPS
-                        n_live++;
-#endif
+                        amax = fmaxf(amax, fabsf(mx));
                         continue;
                     }
                 }
@@ -273,7 +266,8 @@ __global__ __launch_bounds__(64) void k_bestpath(DgParams p) {
                         // edge makes thousands finish early): a vertex of a resident chunk keeps its
                         // result in its slot until the chunk's row store, everything else is in HBM
                         const int yd = d & (DG_BR - 1);
-                        if (S.tag[yd] == d && (S.lens[yd] & DG_BL_DONE) && d >= v_lo) { have = true; sc = S.rscore[yd]; }
+                        if (d == c_top) { have = true; sc = 0.0f; }       // the segment's reference point
+                        else if (S.tag[yd] == d && (S.lens[yd] & DG_BL_DONE) && d >= v_lo) { have = true; sc = S.rscore[yd]; }
                         else {
                             const float2 sg = score[d];
                             if (sg.y == 1.0f) { have = true; sc = sg.x; }
@@ -301,12 +295,7 @@ __global__ __launch_bounds__(64) void k_bestpath(DgParams p) {
                     }
                 }
                 if (bad) break;
-                if (again) {
-#ifdef DG_STAMPS
-                    n_stack++;
-#endif
-                    continue;
-                }
+                if (again) continue;
                 if (lane == 0) {
                     S.stag[n & (DG_SR - 1)] = n;
                     S.sval[n & (DG_SR - 1)] = mx;
@@ -321,9 +310,7 @@ __global__ __launch_bounds__(64) void k_bestpath(DgParams p) {
                 }
                 // (a vertex scored before its chunk is unpacked is scored again at its turn:
                 // same successors, same result)
-#ifdef DG_STAMPS
-                n_live++; n_hbm += hbm;
-#endif
+                amax = fmaxf(amax, fabsf(mx));
                 sp--;
             }
         }
@@ -339,18 +326,98 @@ __global__ __launch_bounds__(64) void k_bestpath(DgParams p) {
 #undef DG_LOAD_REC
 #undef DG_LOAD_ENT
 #undef DG_WRITE_CHUNK
+}
+
+// ---- the recurrence, one wave per (target, segment of k_cuts) -------------------
+// Every path crosses every cut vertex, so inside a segment
+//     score[x] = (best path x -> next cut) + score[next cut]:
+// the segments are swept concurrently, each relative to its own upper cut, and the
+// first-maximum choices (all that the consensus uses) are the reference's as long as
+// the arithmetic is exact, which k_bp_walk verifies from the figures left here.
+__global__ __launch_bounds__(64) void k_bp_sweep(DgParams p) {
+    const uint32_t t = blockIdx.x / p.seg_max, seg = blockIdx.x % p.seg_max;
+    if (dg_failed(p) || !p.tactive[t]) return;
+    const uint32_t *crow = p.cuts + (uint64_t)t * (p.seg_max + 2u);
+    const uint32_t nseg = crow[0];
+    if (seg >= nseg) return;
+    const int lane = threadIdx.x;
+    const uint64_t nb = p.node_base[t];
+    __shared__ DgBpShared S;
+    const int N = (int)p.n_nodes[t];
+    const int c_bot = (int)crow[1 + seg];
+    const int c_top = seg + 1 < nseg ? (int)crow[2 + seg] : -1;
+    float amax = 0.0f;
+    bool bad = false, stuck = false;
+    dg_bp_sweep(S, p.nodes + nb, p.best + nb, p.score + nb, p.pool + p.pool_base[t],
+                c_top >= 0 ? c_top - 1 : N - 1, c_bot, c_top,
+                p.stk + (uint64_t)blockIdx.x * p.stk_words, (int)p.stk_words, lane, amax, bad, stuck);
     if (bad) {                                                    // STACK: the host grows the scratch and re-runs
         if (lane == 0) { dg_fail(p, stuck ? DG_E_INTERNAL : DG_E_STACK); p.st->bad_target = t; }
         return;
     }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    const float a = p.score[nb + c_bot].x;                        // this segment's first vertex, relative to c_top
+    if (lane == 0) { p.bp_stat[2 * (uint64_t)blockIdx.x] = amax; p.bp_stat[2 * (uint64_t)blockIdx.x + 1] = a; }
+}
+
+// ---- walk and segmentation, one wave per target -----------------------------------
+__global__ __launch_bounds__(64) void k_bp_walk(DgParams p) {
+    const uint32_t t = blockIdx.x;
+    if (dg_failed(p) || !p.tactive[t]) return;
+    const int lane = threadIdx.x;
+    const uint64_t nb = p.node_base[t];
+    __shared__ DgBpShared S;
+    __shared__ DgWalkShared W;
+    __shared__ uint32_t s_len, s_nseg;
+    const DgNode *nd = p.nodes + nb;
+    int32_t *best = p.best + nb;
+    const int N = (int)p.n_nodes[t];
+    const int exitv = N - 1;
+    for (int i = lane; i < DG_WR; i += 64) W.wtag[i] = -1;
+    {
+        // Exactness of the segmented sweep: every score is a multiple of 0.5, so fp32 is exact
+        // below 2^23.  A vertex of segment i has the absolute score rel + abs(cut i+1), and a
+        // candidate adds one edge term (|w| <= max(10, reads)); if all of that stays below 2^22
+        // both the reference's absolute arithmetic and the relative one here are exact and pick
+        // the same first maxima.  Otherwise the target is swept again in one piece.
+        const uint32_t *crow = p.cuts + (uint64_t)t * (p.seg_max + 2u);
+        const int nseg = (int)crow[0];
+        bool redo = false;
+        if (nseg > 1) {
+            const float K = (float)(uint32_t)(p.aln_begin[t + 1] - p.aln_begin[t]);
+            const float wmax = K > 10.0f ? K : 10.0f;
+            float acc = 0.0f;
+            for (int i = nseg - 1; i >= 0; i--) {
+                const float m = p.bp_stat[2 * ((uint64_t)t * p.seg_max + i)];
+                const float a = p.bp_stat[2 * ((uint64_t)t * p.seg_max + i) + 1];
+                if (!(m + fabsf(acc) + wmax < 4194304.0f)) redo = true;
+                acc += a;
+            }
+        }
+        if (redo) {
+            float2 *score = p.score + nb;
+            for (int i = lane; i < N; i += 64) score[i] = make_float2(0.0f, 0.0f);
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            float amax = 0.0f;
+            bool bad = false, stuck = false;
+            dg_bp_sweep(S, nd, best, score, p.pool + p.pool_base[t], N - 1, 0, -1,
+                        p.stk + (uint64_t)t * p.seg_max * p.stk_words, (int)p.stk_words, lane, amax, bad, stuck);
+            if (bad) {
+                if (lane == 0) { dg_fail(p, stuck ? DG_E_INTERNAL : DG_E_STACK); p.st->bad_target = t; }
+                return;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        }
+    }
 #ifdef DG_STAMPS
-    const unsigned long long t_sweep = clock64();
+    const unsigned long long t_begin = clock64(), t_sweep = t_begin;
+    const unsigned long long n_live = 0, n_stack = 0, n_hbm = 0;
 #endif
 
     // :443-456 walk the best edges from enter; :327-373 segmentation.  Every lane runs the
     // (uniform) walk so that all of them can stage; lane 0 keeps the results.
     uint8_t *tmp = p.cns_tmp + nb;
-    int32_t *segs = p.stk + (uint64_t)t * p.stk_words;      // (range0, range1) pairs
+    int32_t *segs = p.stk + (uint64_t)t * p.seg_max * p.stk_words;      // (range0, range1) pairs
     {
         const uint8_t eb = nd[0].base, xb = nd[exitv].base;
         const int minw = p.min_weight;
@@ -367,15 +434,15 @@ __global__ __launch_bounds__(64) void k_bestpath(DgParams p) {
                 if (id < N) {
                     const uint4 h = *reinterpret_cast<const uint4 *>(&nd[id]);
                     const int b = best[id];
-                    const int xw = id & (DG_BR - 1);
-                    S.wtag[xw] = id; S.wbest[xw] = b; S.wbase[xw] = (int)(h.y & 0xffu); S.wweight[xw] = (int)h.z;
+                    const int xw = id & (DG_WR - 1);
+                    W.wtag[xw] = id; W.wbest[xw] = b; W.wbase[xw] = (int)(h.y & 0xffu); W.wweight[xw] = (int)h.z;
                 }
                 cs++;
             }
-            const int xw = v & (DG_BR - 1);
+            const int xw = v & (DG_WR - 1);
             int nxt, w;
             uint8_t base;
-            const int wt = S.wtag[xw], wb = S.wbest[xw], wa = S.wbase[xw], ww = S.wweight[xw];
+            const int wt = W.wtag[xw], wb = W.wbest[xw], wa = W.wbase[xw], ww = W.wweight[xw];
             if (__builtin_amdgcn_readfirstlane(wt) == v) {
                 nxt = __builtin_amdgcn_readfirstlane(wb); base = (uint8_t)__builtin_amdgcn_readfirstlane(wa);
                 w = __builtin_amdgcn_readfirstlane(ww);
@@ -386,8 +453,8 @@ __global__ __launch_bounds__(64) void k_bestpath(DgParams p) {
                 w = __builtin_amdgcn_readfirstlane((int)h.z);
             }
             if (!(base == eb || base == xb)) {
-                if (lane == 0) S.wbuf[idx & 63] = base;
-                if ((idx & 63) == 63) tmp[(idx & ~63) + lane] = S.wbuf[lane];
+                if (lane == 0) W.wbuf[idx & 63] = base;
+                if ((idx & 63) == 63) tmp[(idx & ~63) + lane] = W.wbuf[lane];
                 if (!met && w >= minw) { offs = idx; met = true; }
                 else if (met && w < minw) {
                     met = false;
@@ -407,7 +474,7 @@ __global__ __launch_bounds__(64) void k_bestpath(DgParams p) {
             else ovf = true;
         }
         // only the bases some segment covers are shipped
-        if (lane < (idx & 63)) tmp[(idx & ~63) + lane] = S.wbuf[lane];     // the last, partial row
+        if (lane < (idx & 63)) tmp[(idx & ~63) + lane] = W.wbuf[lane];     // the last, partial row
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         if (lane == 0) {
             if (ovf) dg_fail(p, DG_E_STACK);

@@ -778,6 +778,7 @@ __global__ __launch_bounds__(PF ? 128 : 64) __attribute__((amdgpu_waves_per_eu(8
         have_next = false;
         qh++;
         bool scalar = false, merged = false;
+        (void)merged;
 #ifdef DG_STAMPS
         unsigned long long ts_pre = 0, ts_in = 0, acc_grp = 0, n_grp_in = 0, n_grp_out = 0;
         const unsigned long long ts0 = clock64();

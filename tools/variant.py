@@ -1,7 +1,8 @@
 import sys, os
-sys.path.insert(0, os.getcwd())
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 from pbdagcon_amd import capi, synth
-capi.LIB_PATH = os.path.join(os.getcwd(), "pbdagcon_amd", sys.argv[1])
+capi.LIB_PATH = os.path.join(ROOT, "pbdagcon_amd", sys.argv[1])
 b = synth.make_batch(1000, 10000, 40, seed=1000)
 ctx = capi.Context(min_cov=6, min_len=500, trim=50)
 ctx.upload(b); ctx.run(); r0 = ctx.fetch(); ctx.run(); r1 = ctx.fetch()
