@@ -55,6 +55,8 @@ typedef enum dagcon_status {
 #define DAGCON_FLAG_STOP_AFTER_BUILD 2u /* debug: stop after addAln (no merge, no consensus) so that
                                            dagcon_debug_graph shows the graph before mergeNodes */
 #define DAGCON_FLAG_STOP_AFTER_MERGE 4u /* debug: stop after mergeNodes */
+#define DAGCON_FLAG_DEBUG_RESWEEP 16u   /* debug: treat the segmented bestPath sweep as inexact, so that
+                                           every target takes the one-piece re-sweep (tests only) */
 
 /* Mirrors ProgramOpts (src/cpp/ProgramOpts.hpp:8-36) for this path. */
 typedef struct dagcon_opts {
@@ -65,7 +67,11 @@ typedef struct dagcon_opts {
     int32_t  min_weight; /* consensus minWeight; <0 means "= min_cov" as main.cpp:261,279 does */
     int32_t  device;     /* HIP device ordinal */
     uint32_t flags;
-    uint32_t reserved[2];
+    uint32_t max_segments; /* workers per target for mergeNodes/bestPath: a target is swept in up to
+                              this many pieces, split at backbone vertices every read passes
+                              through (the result does not depend on it).  0 = automatic,
+                              1 = one sequential sweep per target, at most 64 */
+    uint32_t min_segment_len; /* shortest backbone stretch given a worker of its own; 0 = default (768) */
 } dagcon_opts;
 
 /* Defaults of pbdagcon (main.cpp:181-211): -c 6 -m 500 -t 50. */
@@ -128,7 +134,7 @@ typedef struct dagcon_timings {
     uint64_t n_columns;         /* normalised, trimmed columns threaded into graphs */
     uint64_t n_nodes;           /* graph vertices before merging, all targets */
     uint32_t reruns;            /* times the batch was re-run after growing the workspace */
-    uint32_t reserved;
+    uint32_t merge_segments;    /* pieces the targets of the batch were swept in, all targets */
 } dagcon_timings;
 
 typedef struct dagcon_ctx dagcon_ctx;

@@ -22,6 +22,7 @@ ERR_NAMES = {
 FLAG_RAW_ALIGNMENTS = 1
 FLAG_STOP_AFTER_BUILD = 2
 FLAG_STOP_AFTER_MERGE = 4
+FLAG_DEBUG_RESWEEP = 16
 MAX_COVERAGE = 4094
 
 EXPORTS = [
@@ -41,7 +42,7 @@ class DagconError(RuntimeError):
 class Opts(C.Structure):
     _fields_ = [("min_cov", C.c_uint32), ("min_len", C.c_uint32), ("trim", C.c_uint32),
                 ("min_weight", C.c_int32), ("device", C.c_int32), ("flags", C.c_uint32),
-                ("reserved", C.c_uint32 * 2)]
+                ("max_segments", C.c_uint32), ("min_segment_len", C.c_uint32)]
 
 
 class Batch(C.Structure):
@@ -64,7 +65,7 @@ class Timings(C.Structure):
                 ("ms_merge", C.c_float), ("ms_bestpath", C.c_float),
                 ("algorithmic_bytes", C.c_uint64), ("consensus_bases", C.c_uint64),
                 ("n_alignments", C.c_uint64), ("n_columns", C.c_uint64), ("n_nodes", C.c_uint64),
-                ("reruns", C.c_uint32), ("reserved", C.c_uint32)]
+                ("reruns", C.c_uint32), ("merge_segments", C.c_uint32)]
 
 
 class GraphDump(C.Structure):
@@ -187,11 +188,13 @@ class HostBatch:
 class Context:
     """dagcon_ctx handle.  One per GPU; single-owner."""
 
-    def __init__(self, min_cov=6, min_len=500, trim=50, min_weight=-1, device=0, flags=0):
+    def __init__(self, min_cov=6, min_len=500, trim=50, min_weight=-1, device=0, flags=0, max_segments=0,
+                 min_segment_len=0):
         self.L = load()
         o = Opts()
         o.min_cov, o.min_len, o.trim, o.min_weight = min_cov, min_len, trim, min_weight
-        o.device, o.flags = device, flags
+        o.device, o.flags, o.max_segments = device, flags, max_segments
+        o.min_segment_len = min_segment_len
         self.opts = o
         self.h = C.c_void_p()
         rc = self.L.dagcon_create(C.byref(o), C.byref(self.h))

@@ -177,7 +177,7 @@ void fill_params(Ctx *c, DgParams &p) {
     // the prefetch wave pays while the chip has idle wave slots; past ~1.5 workers per SIMD the
     // workers hide each other's latency and it only takes issue slots from them
     { const char *e = getenv("DAGCON_PF_AHEAD"); p.pf_ahead = e ? (uint32_t)atoi(e) : ((uint64_t)c->T * c->seg_max >= 1536 ? 0u : 48u); }
-    p.seg_max = c->seg_max; p.cuts = (uint32_t *)c->d_cuts.p; p.bp_stat = (float *)c->d_bp_stat.p;
+    p.seg_max = c->seg_max; p.seg_min = c->opts.min_segment_len ? c->opts.min_segment_len : 768u; p.cuts = (uint32_t *)c->d_cuts.p; p.bp_stat = (float *)c->d_bp_stat.p;
     p.cns = (uint8_t *)c->d_cns.p; p.cns_cap = c->cns_cap;
     p.cns_off = (uint64_t *)c->d_cns_off.p; p.cns_len = (uint32_t *)c->d_cns_len.p;
     p.seg_first = (uint64_t *)c->d_seg_first.p; p.n_seg = (uint32_t *)c->d_n_seg.p;
@@ -313,7 +313,8 @@ int dagcon_upload(dagcon_ctx *ctx, const dagcon_batch *b) {
     c->T = T;
     // merge workers per target: about one chip's worth of resident waves (8 per SIMD x 1024
     // SIMDs) over the batch, never fewer than 8 nor more than 32 per target
-    if (c->seg_env) c->seg_max = c->seg_env;
+    if (c->opts.max_segments) c->seg_max = c->opts.max_segments > 64u ? 64u : c->opts.max_segments;
+    else if (c->seg_env) c->seg_max = c->seg_env;
     else { uint32_t sm = T ? 8192u / T : 8u; c->seg_max = sm < 8u ? 8u : sm > 32u ? 32u : sm; }
     c->h_tlen.assign(b->tlen, b->tlen + T);
     c->h_aln_begin.assign(T + 1, 0);
@@ -523,6 +524,7 @@ int dagcon_fetch(dagcon_ctx *ctx, dagcon_results *res) {
     c->tm.n_alignments = c->A;
     c->tm.n_columns = c->h_st.n_columns;
     c->tm.n_nodes = c->h_st.node_need;
+    c->tm.merge_segments = c->h_st.n_mseg;
     res->n_targets = T;
     res->n_segments = c->r_range0.size();
     res->seg_begin = c->r_seg_begin.data();

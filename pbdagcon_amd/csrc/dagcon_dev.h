@@ -22,6 +22,7 @@
 // DgParams::flags: bits 0..2 are dagcon_opts.flags; internal bits from 8 up
 #define DG_F_RAW      1u
 #define DG_F_A1_ONLY  8u   // dagcon_normalize: no graph follows, skip the backbone conformity check
+#define DG_F_RESWEEP  16u  // DAGCON_FLAG_DEBUG_RESWEEP
 
 // status bits (DgStatus::err_flags)
 #define DG_E_BADCHAR     0x001u  // byte outside printable ASCII in an alignment string
@@ -39,7 +40,7 @@ struct DgStatus {
     uint32_t err_flags;
     uint32_t bad_aln;
     uint32_t bad_target;
-    uint32_t pad;
+    uint32_t n_mseg;               // segments of the merge / bestPath sweeps, all targets (k_cuts)
     unsigned long long norm_top;   // bump cursor into the column arena (uint16 units)
     unsigned long long node_need;  // exact vertex count of the batch (set by carve)
     unsigned long long pool_need;  // exact pool words of the batch (set by carve)
@@ -123,6 +124,7 @@ struct DgParams {
     uint32_t growth_pct;           // pool growth region as % of the initial adjacency words
     uint32_t pf_ahead;             // vertices the prefetch wave runs ahead of the sweep (0 = off)
     uint32_t seg_max;              // most segments a target's merge sweep is split into (k_cuts)
+    uint32_t seg_min;              // shortest backbone stretch worth a worker of its own
     uint32_t *cuts;                // [T][seg_max + 2]: segment count, first vertex of each segment
     float *bp_stat;                // [T][seg_max][2]: largest |score| of the segment, score of its first vertex
     // ---- outputs ----

@@ -382,7 +382,7 @@ __global__ __launch_bounds__(64) void k_bp_walk(DgParams p) {
         // the same first maxima.  Otherwise the target is swept again in one piece.
         const uint32_t *crow = p.cuts + (uint64_t)t * (p.seg_max + 2u);
         const int nseg = (int)crow[0];
-        bool redo = false;
+        bool redo = nseg > 1 && (p.flags & DG_F_RESWEEP);
         if (nseg > 1) {
             const float K = (float)(uint32_t)(p.aln_begin[t + 1] - p.aln_begin[t]);
             const float wmax = K > 10.0f ? K : 10.0f;

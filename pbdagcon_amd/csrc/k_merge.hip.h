@@ -679,7 +679,6 @@ __device__ inline bool dgw_merge_in_group(DgGraph &g, int n, const DgNode &nn, u
 // mergeInNodes (the previous segment's worker does that as its last act) and
 // ends when it dequeues the next cut vertex.
 // row of p.cuts: [0] = number of segments, [1 + s] = first vertex of segment s.
-#define DG_SEG_MIN 768u          // shortest backbone stretch worth a worker of its own
 __global__ __launch_bounds__(64) void k_cuts(DgParams p) {
     const uint32_t t = blockIdx.x;
     if (dg_failed(p) || !p.tactive[t]) return;
@@ -694,7 +693,7 @@ __global__ __launch_bounds__(64) void k_cuts(DgParams p) {
     int kg = 0;
     for (int i = lane; i < en.out_len; i += 64) kg += (int)pool[en.out_off + 2 * i + 1];
     for (int o = 32; o; o >>= 1) kg += __shfl_xor(kg, o);
-    uint32_t want = blen / DG_SEG_MIN;
+    uint32_t want = blen / p.seg_min;
     if (want > p.seg_max) want = p.seg_max;
     if (want < 1) want = 1;
     uint32_t nseg = 1;
@@ -716,7 +715,7 @@ __global__ __launch_bounds__(64) void k_cuts(DgParams p) {
         }
         if (found) { if (lane == 0) row[1 + nseg] = found; nseg++; }
     }
-    if (lane == 0) row[0] = nseg;
+    if (lane == 0) { row[0] = nseg; atomicAdd(&p.st->n_mseg, nseg); }
 }
 
 // ---- mergeNodes (AlnGraphBoost.cpp:129-160): one wave per (target, segment) ----

@@ -137,6 +137,65 @@ def test_graph_adjacency_matches_oracle(gpu_ctx_factory, merge):
             assert g["inn"] == [o2d[s] for s, _ in eie], f"target {t} vertex {o}: in list"
 
 
+def test_segmented_sweeps_are_exact(gpu_ctx_factory):
+    """mergeNodes and bestPath are split at backbone vertices every read passes through
+    (k_cuts) and the pieces are swept concurrently.  1, 3, 8 and 32 pieces per target all give
+    the oracle's consensus, also with the one-piece bestPath re-sweep forced: full-span reads
+    (cuts everywhere) and partial spans (cuts only where all reads overlap, often none)."""
+    full = synth.make_batch(6, 6000, 30, seed=31000)
+    part = synth.make_batch(6, 0, 24, seed=32000, min_span=0.5,
+                            tlens=np.array([5000, 7000, 9000, 3000, 12000, 6000]))
+    for batch, trim in ((full, 50), (part, 10)):
+        exp = oracle_batch(batch, 6, 500, trim)
+        nseg = {}
+        for ms, flags in ((1, 0), (3, 0), (8, 0), (32, 0), (8, capi.FLAG_DEBUG_RESWEEP)):
+            ctx = gpu_ctx_factory(min_cov=6, min_len=500, trim=trim, max_segments=ms, flags=flags)
+            assert ctx.consensus(batch) == exp, f"max_segments={ms} flags={flags}"
+            nseg[ms] = ctx.timings()["merge_segments"]
+        assert nseg[1] == batch.n_targets
+        if batch is full:
+            assert nseg[8] == 6 * 7 and nseg[3] == 6 * 3       # 6000 / 768 = 7 stretches wanted and found
+        assert nseg[32] >= nseg[8] >= nseg[3] >= nseg[1]
+
+
+@pytest.mark.parametrize("seed", [11, 12])
+def test_segments_on_adversarial_little_pileups(gpu_ctx_factory, seed):
+    """Cuts every few bases on tiny-alphabet pileups: merge groups, turned-around edges and
+    long insertion runs right next to the cut vertices; graph after merge and consensus."""
+    rng = np.random.default_rng(seed)
+    targets = []
+    for i in range(120):
+        tl = int(rng.integers(20, 160))
+        alph = [b"AC", b"ACGT", b"A"][i % 3]
+        alns, bb = random_target(rng, tl, int(rng.integers(2, 10)), alphabet=alph,
+                                 sub=float(rng.uniform(0, 0.1)), ins=float(rng.uniform(0, 0.25)),
+                                 dele=float(rng.uniform(0, 0.12)), full_span=(i % 4 != 0))
+        targets.append((tl, alns, bb))
+    batch = batch_from_targets(targets)
+    for kw in [dict(min_cov=0, min_len=0, trim=0, min_weight=0),
+               dict(min_cov=2, min_len=10, trim=2, min_weight=1)]:
+        exp = oracle_batch(batch, kw["min_cov"], kw["min_len"], kw["trim"], kw["min_weight"])
+        ctx = gpu_ctx_factory(max_segments=16, min_segment_len=4, **kw)
+        assert ctx.consensus(batch) == exp
+        assert ctx.timings()["merge_segments"] > 3 * batch.n_targets       # the cuts were really used
+    # and the merged graph itself, vertex by vertex
+    ctx = gpu_ctx_factory(min_cov=0, min_len=0, trim=0, min_weight=0, max_segments=16, min_segment_len=4,
+                          flags=capi.FLAG_STOP_AFTER_MERGE)
+    ctx.consensus(batch)
+    for t in range(0, batch.n_targets, 5):
+        got = ctx.debug_graph(t)
+        exp, o2d = _oracle_graph(batch, t, 0, 0, True)
+        assert len(got) == len(exp)
+        for o, (eb, ew, ec, ed, eoe, eie) in enumerate(exp):
+            g = got[o2d[o]]
+            assert g["deleted"] == ed
+            if ed:
+                continue
+            assert (g["base"], g["weight"]) == (eb, ew)
+            assert g["out"] == [(o2d[d], c) for d, c in eoe], f"target {t} vertex {o}: out list"
+            assert g["inn"] == [o2d[s] for s, _ in eie], f"target {t} vertex {o}: in list"
+
+
 @pytest.mark.parametrize("seed", [1, 2, 3])
 def test_random_small_targets(gpu_ctx_factory, seed):
     """Hundreds of adversarial little pileups: tiny alphabets, ragged spans, long
