@@ -1,7 +1,7 @@
 // dagcon_api.hip -- host side of the C ABI (include/dagcon.h).
 //
 // Owns the HIP stream, the HBM arenas and the launch sequence of the hot path
-//   a1 k_count, k_normalize | a2 k_carve, k_init_nodes, k_emit, k_lists |
+//   a1 k_count, k_norm_*    | a2 k_carve, k_init_nodes, k_emit, k_lists |
 //   b  k_merge              | c  k_bestpath
 // There is no CPU fallback anywhere in this file: without a HIP device
 // dagcon_create fails with DAGCON_ERR_NO_DEVICE.
@@ -43,11 +43,16 @@ struct Ctx {
     std::vector<uint32_t> h_tlen, h_aln_len, h_aln_start, h_aln_tgt;
     std::vector<uint64_t> h_aln_begin, h_aln_off, h_mat_base, h_bbv_base, h_bb_off;
     std::vector<uint8_t> h_tactive;
+    std::vector<uint32_t> h_ch_base, h_ch_aln;      // chunk tables of k_norm_*
+    uint32_t n_chunks = 0;
+    uint64_t tmp_main = 0, tmp_cap = 0;
 
     // device buffers
     DevBuf d_q, d_t, d_aln_off, d_aln_len, d_aln_start, d_aln_tgt, d_tlen, d_aln_begin, d_tactive,
         d_bb, d_bb_off, d_mat_base, d_bbv_base;
     DevBuf d_nmis, d_norm_off, d_n_lo, d_n_hi, d_n_start, d_n_ins, d_n_del, d_norm;
+    DevBuf d_ch_aln, d_ch_base, d_ch_k0, d_ch_next, d_ch_w, d_ch_tb, d_ch_flag, d_ch_src, d_ch_out, d_ch_adv,
+        d_n_lb, d_norm_tmp;
     DevBuf d_node_base, d_n_nodes, d_pool_base, d_pool_size, d_pool_top, d_t_nins;
     DevBuf d_matA, d_matD, d_matC, d_cov, d_gcount, d_gbase, d_bid;
     DevBuf d_nodes, d_best, d_queue, d_score, d_cns_tmp;
@@ -163,6 +168,14 @@ void fill_params(Ctx *c, DgParams &p) {
     p.n_start = (uint32_t *)c->d_n_start.p; p.n_ins = (uint32_t *)c->d_n_ins.p;
     p.n_del = (uint32_t *)c->d_n_del.p;
     p.norm = (uint16_t *)c->d_norm.p; p.norm_cap = c->norm_cap;
+    p.ch_aln = (const uint32_t *)c->d_ch_aln.p; p.ch_base = (const uint32_t *)c->d_ch_base.p;
+    p.n_chunks = c->n_chunks;
+    p.ch_k0 = (uint32_t *)c->d_ch_k0.p; p.ch_next = (uint32_t *)c->d_ch_next.p;
+    p.ch_w = (uint32_t *)c->d_ch_w.p; p.ch_tb = (uint32_t *)c->d_ch_tb.p;
+    p.ch_flag = (uint32_t *)c->d_ch_flag.p; p.ch_src = (uint64_t *)c->d_ch_src.p;
+    p.ch_out = (uint32_t *)c->d_ch_out.p; p.ch_adv = (uint32_t *)c->d_ch_adv.p;
+    p.n_lb = (uint32_t *)c->d_n_lb.p; p.norm_tmp = (uint16_t *)c->d_norm_tmp.p;
+    p.tmp_main = c->tmp_main; p.tmp_cap = c->tmp_cap;
     p.node_base = (uint64_t *)c->d_node_base.p; p.n_nodes = (uint32_t *)c->d_n_nodes.p;
     p.pool_base = (uint64_t *)c->d_pool_base.p; p.pool_size = (uint32_t *)c->d_pool_size.p;
     p.pool_top = (uint32_t *)c->d_pool_top.p; p.t_nins = (uint32_t *)c->d_t_nins.p;
@@ -186,6 +199,17 @@ void fill_params(Ctx *c, DgParams &p) {
     p.st = (DgStatus *)c->d_st.p;
 }
 
+// stage a1: count, chunked normalizeGaps + trimAln, and the sequential kernel for what is left
+void launch_normalize(Ctx *c, const DgParams &p) {
+    hipStream_t s = c->stream;
+    if (c->A == 0) return;
+    hipLaunchKernelGGL(k_count, dim3(c->A), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(k_norm_chunk, dim3((c->n_chunks + 63) / 64), dim3(64), 0, s, p);
+    hipLaunchKernelGGL(k_norm_scan, dim3((c->A + 63) / 64), dim3(64), 0, s, p);
+    hipLaunchKernelGGL(k_norm_finish, dim3((c->n_chunks + 63) / 64), dim3(64), 0, s, p);
+    hipLaunchKernelGGL(k_normalize_slow, dim3((c->A + 63) / 64), dim3(64), 0, s, p);
+}
+
 int launch_all(Ctx *c) {
     int r = ensure_arenas(c);
     if (r != DAGCON_OK) return r;
@@ -197,11 +221,7 @@ int launch_all(Ctx *c) {
     HIPCHK(c, hipMemsetAsync(c->d_n_seg.p, 0, (size_t)c->T * 4, s));
     if (c->mat_cells) HIPCHK(c, hipMemsetAsync(c->d_matC.p, 0, c->mat_cells * 4, s));
     HIPCHK(c, hipEventRecord(c->ev[0], s));
-    if (c->A > 0) {
-        hipLaunchKernelGGL(k_count, dim3(c->A), dim3(256), 0, s, p);
-        hipLaunchKernelGGL(k_normalize, dim3((c->A + DG_NLPW - 1) / DG_NLPW), dim3(64), 0, s, p);
-        hipLaunchKernelGGL(k_normalize_slow, dim3((c->A + 63) / 64), dim3(64), 0, s, p);
-    }
+    launch_normalize(c, p);
     HIPCHK(c, hipEventRecord(c->ev[1], s));
     if (c->mat_cells) {
         HIPCHK(c, hipMemsetAsync(c->d_matA.p, 0, c->mat_cells * 4, s));
@@ -285,7 +305,7 @@ void dagcon_destroy(dagcon_ctx *ctx) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     DevBuf *all[] = {&c->d_q, &c->d_t, &c->d_aln_off, &c->d_aln_len, &c->d_aln_start, &c->d_aln_tgt,
                      &c->d_tlen, &c->d_aln_begin, &c->d_tactive, &c->d_bb, &c->d_bb_off, &c->d_mat_base,
-                     &c->d_bbv_base, &c->d_nmis, &c->d_norm_off, &c->d_n_lo, &c->d_n_hi, &c->d_n_start,
+                     &c->d_bbv_base, &c->d_nmis, &c->d_norm_off, &c->d_n_lo, &c->d_n_hi, &c->d_n_start, &c->d_ch_aln, &c->d_ch_base, &c->d_ch_k0, &c->d_ch_next, &c->d_ch_w, &c->d_ch_tb, &c->d_ch_flag, &c->d_ch_src, &c->d_ch_out, &c->d_ch_adv, &c->d_n_lb, &c->d_norm_tmp,
                      &c->d_n_ins, &c->d_n_del, &c->d_norm, &c->d_node_base, &c->d_n_nodes,
                      &c->d_pool_base, &c->d_pool_size, &c->d_pool_top, &c->d_t_nins, &c->d_matA, &c->d_matD,
                      &c->d_matC, &c->d_cov, &c->d_gcount, &c->d_gbase, &c->d_bid, &c->d_nodes,
@@ -369,6 +389,19 @@ int dagcon_upload(dagcon_ctx *ctx, const dagcon_batch *b) {
     if (c->h_aln_len.size() > 0xFFFFFFF0ull) return fail(c, DAGCON_ERR_UNSUPPORTED, "too many alignments");
     c->A = (uint32_t)c->h_aln_len.size();
     c->blob_bytes = b->blob_bytes;
+    // windows of DG_NCH input columns: the units of the chunked normalizeGaps
+    c->h_ch_base.assign((size_t)c->A + 1, 0);
+    c->h_ch_aln.clear();
+    for (uint32_t a = 0; a < c->A; a++) {
+        const uint32_t nw = std::max<uint32_t>(1u, (c->h_aln_len[a] + DG_NCH - 1) / DG_NCH);
+        c->h_ch_base[a] = (uint32_t)c->h_ch_aln.size();
+        if (c->h_ch_aln.size() + nw > 0xFFFFFFF0ull) return fail(c, DAGCON_ERR_UNSUPPORTED, "too many alignment columns");
+        c->h_ch_aln.insert(c->h_ch_aln.end(), nw, a);
+    }
+    c->h_ch_base[c->A] = (uint32_t)c->h_ch_aln.size();
+    c->n_chunks = (uint32_t)c->h_ch_aln.size();
+    c->tmp_main = (2ull * b->blob_bytes + 8ull * c->n_chunks + 15ull) & ~7ull;
+    c->tmp_cap = c->tmp_main + std::max<uint64_t>(c->tmp_main / 16, 1ull << 20);
 
     // inputs -> HBM
     ENSURE(c, c->d_q, b->blob_bytes);
@@ -392,12 +425,20 @@ int dagcon_upload(dagcon_ctx *ctx, const dagcon_batch *b) {
     if ((r = upload_vec(c, c->d_bb_off, c->h_bb_off))) return r;
     if ((r = upload_vec(c, c->d_mat_base, c->h_mat_base))) return r;
     if ((r = upload_vec(c, c->d_bbv_base, c->h_bbv_base))) return r;
+    if ((r = upload_vec(c, c->d_ch_base, c->h_ch_base))) return r;
+    if ((r = upload_vec(c, c->d_ch_aln, c->h_ch_aln))) return r;
 
     // work arrays whose size the host knows
     const size_t A4 = (size_t)c->A * 4, T4 = (size_t)T * 4;
     ENSURE(c, c->d_nmis, A4); ENSURE(c, c->d_norm_off, (size_t)c->A * 8);
     ENSURE(c, c->d_n_lo, A4); ENSURE(c, c->d_n_hi, A4); ENSURE(c, c->d_n_start, A4);
-    ENSURE(c, c->d_n_ins, A4); ENSURE(c, c->d_n_del, A4);
+    ENSURE(c, c->d_n_ins, A4); ENSURE(c, c->d_n_del, A4); ENSURE(c, c->d_n_lb, A4);
+    {
+        const size_t C4 = (size_t)c->n_chunks * 4;
+        ENSURE(c, c->d_ch_k0, C4); ENSURE(c, c->d_ch_next, C4); ENSURE(c, c->d_ch_w, C4); ENSURE(c, c->d_ch_tb, C4);
+        ENSURE(c, c->d_ch_flag, C4); ENSURE(c, c->d_ch_src, 2 * C4); ENSURE(c, c->d_ch_out, C4); ENSURE(c, c->d_ch_adv, C4);
+        ENSURE(c, c->d_norm_tmp, c->tmp_cap * sizeof(uint16_t));
+    }
     ENSURE(c, c->d_node_base, (size_t)T * 8); ENSURE(c, c->d_n_nodes, T4);
     ENSURE(c, c->d_pool_base, (size_t)T * 8); ENSURE(c, c->d_pool_size, T4); ENSURE(c, c->d_pool_top, T4);
     ENSURE(c, c->d_t_nins, T4);
@@ -593,11 +634,7 @@ static int normalize_impl(Ctx *c, dagcon_ctx *ctx, uint32_t n, const uint32_t *a
         fill_params(c, p);
         p.flags |= DG_F_A1_ONLY;
         HIPCHK(c, hipMemsetAsync(c->d_st.p, 0, sizeof(DgStatus), c->stream));
-        if (c->A) {
-            hipLaunchKernelGGL(k_count, dim3(c->A), dim3(256), 0, c->stream, p);
-            hipLaunchKernelGGL(k_normalize, dim3((c->A + DG_NLPW - 1) / DG_NLPW), dim3(64), 0, c->stream, p);
-            hipLaunchKernelGGL(k_normalize_slow, dim3((c->A + 63) / 64), dim3(64), 0, c->stream, p);
-        }
+        launch_normalize(c, p);
         HIPCHK(c, hipGetLastError());
         if ((r = read_status(c))) return r;
         if ((c->h_st.err_flags & DG_E_NORM_OVF) && attempt < 3) {

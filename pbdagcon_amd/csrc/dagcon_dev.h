@@ -47,6 +47,7 @@ struct DgStatus {
     unsigned long long cns_top;    // bump cursor into the consensus blob
     unsigned long long seg_top;    // bump cursor into the segment arrays
     unsigned long long n_columns;  // normalised, trimmed columns
+    unsigned long long ovf_top;    // bump cursor into the re-run region of the chunk scratch (uint16 units)
     unsigned long long dbg[16];     // diagnostic build only (DG_STAMPS): cycle / visit counters of target 0
 };
 
@@ -97,6 +98,19 @@ struct DgParams {
     uint32_t *n_lo, *n_hi, *n_start, *n_ins, *n_del;
     uint16_t *norm;                // column arena: low byte q, high byte t
     uint64_t norm_cap;
+    // ---- chunked normalizeGaps (k_norm_*): window c of alignment a is chunk ch_base[a] + c ----
+    const uint32_t *ch_aln;        // [n_chunks] alignment of the chunk
+    const uint32_t *ch_base;       // [A + 1]
+    uint32_t n_chunks;
+    uint32_t *ch_k0;               // first input column, DG_CH_NONE: no chunk starts in this window
+    uint32_t *ch_next;             // window (of the alignment) the next chunk starts in
+    uint32_t *ch_w, *ch_tb;        // columns written, of which with a target base
+    uint32_t *ch_flag;             // 1 = the alignment goes to k_normalize_slow
+    uint64_t *ch_src;              // where the chunk's columns are, in norm_tmp
+    uint32_t *ch_out, *ch_adv;     // after k_norm_scan: column index / target bases in front, DG_CH_NONE: no chunk
+    uint32_t *n_lb;                // [A] target bases trimAln took off the left end
+    uint16_t *norm_tmp;            // chunk scratch: 2 columns per input column, then the re-run region
+    uint64_t tmp_main, tmp_cap;    // uint16 units: start of the re-run region, end of the scratch
     // ---- per target work arrays ----
     uint64_t *node_base;
     uint32_t *n_nodes;

@@ -1,8 +1,9 @@
 // k_build.hip.h -- stage (a): alignment strings -> alignment DAG in HBM.
 //
 //   k_count      a1  mismatch count per alignment (sizes the column buffer), byte validation
-//   k_normalize  a1  normalizeGaps (Alignment.cpp:131-217) + trimAln (:219-242), one lane per
-//                    alignment; also records the insertion run length per (position, read)
+//   k_norm_*     a1  normalizeGaps (Alignment.cpp:131-217) + trimAln (:219-242) in chunks of ~1 k
+//                    input columns, one lane per chunk; also records the insertion run length
+//                    per (position, read).  k_normalize_slow: whole alignments, sequential.
 //   k_carve      a2  exact vertex / pool needs per target, exclusive scans -> arena offsets
 //   k_groups     a2  per backbone position: exclusive scan of insertion run lengths over reads
 //   k_gscan      a2  per target: exclusive scan over positions -> position-ordered vertex ids
@@ -63,23 +64,22 @@ __global__ __launch_bounds__(256) void k_count(DgParams p) {
 }
 
 // ---------------------------------------------------------------------------
-// k_normalize: one lane per alignment; sequential by nature (gap pushing is a
-// left-to-right rewrite with unbounded look-ahead), parallel over alignments.
-// Columns are uint16: low byte = query char, high byte = target char.
+// normalizeGaps.  Columns are uint16: low byte = query char, high byte = target char.
 //
-// The fast kernel streams: 16 input columns per 16-byte load, expanded into a
-// per-lane LDS window; the push loop (Alignment.cpp:165-198) runs on the window
-// with its two monotone look-ahead cursors and pauses when a look-ahead reaches
-// the end of the window (its steps are idempotent, see below); finished columns
-// leave as plain 2-byte stores.  An alignment whose look-ahead outgrows the
-// window (a gap run of ~100 columns) is flagged and redone by
+// The rewrite streams: 16 input columns per 16-byte load, expanded into a per-lane LDS
+// window; the push loop (Alignment.cpp:165-198) runs on the window with its two monotone
+// look-ahead cursors and pauses when a look-ahead reaches the end of the window (its steps
+// are idempotent, see dg_norm_run); finished columns leave 8 at a time.  An alignment whose
+// look-ahead outgrows the window (a gap run of ~100 columns) is flagged and redone by
 // k_normalize_slow, the same algorithm on HBM.
 // ---------------------------------------------------------------------------
 #define DG_COL(qb, tb) ((uint16_t)((uint16_t)(qb) | ((uint16_t)(tb) << 8)))
 #define DG_Q(c) ((uint8_t)((c) & 0xff))
 #define DG_T(c) ((uint8_t)((c) >> 8))
+#ifndef DG_NW
 #define DG_NW 128u            // LDS window: columns per lane (power of two)
 #define DG_NW_STRIDE 130u     // uint16 per lane row: 65 dwords, odd, so lanes spread over banks
+#endif
 #define DG_REDO 0xFFFFFFFFu   // n_hi marker: redo on the slow path
 
 // trimAln, column counts, conformity, insertion runs: what follows normalizeGaps for
@@ -149,33 +149,65 @@ __device__ inline void dg_finish_alignment(const DgParams &p, uint32_t a, uint16
     }
 }
 
-// alignments per wave: the kernel is bound by the latency of one lane's dependent chain, not by
-// lanes, so a wave takes DG_NLPW alignments and several waves share a SIMD
-#ifndef DG_NLPW
-#define DG_NLPW 64
-#endif
-__global__ __launch_bounds__(64) void k_normalize(DgParams p) {
-    __shared__ uint16_t s_win[DG_NLPW * DG_NW_STRIDE];
-    if (threadIdx.x >= DG_NLPW) return;
-    const uint32_t a = blockIdx.x * DG_NLPW + threadIdx.x;
-    if (a >= p.A) return;
-    if (dg_failed(p)) return;
-    const uint64_t off = p.aln_off[a];
-    const uint32_t len = p.aln_len[a];
-    const uint8_t *q = p.q + off, *t = p.t + off;
-    uint16_t *buf = p.norm + p.norm_off[a];
-    if (p.flags & DG_F_RAW) { p.n_hi[a] = DG_REDO; return; }   // raw columns: the slow kernel copies them
-    uint16_t *win = s_win + threadIdx.x * DG_NW_STRIDE;
-#define DG_W(x) win[(x) & (DG_NW - 1u)]
+// ---------------------------------------------------------------------------
+// Chunked normalizeGaps: k_norm_chunk -> k_norm_scan -> k_norm_finish.
+//
+// The gap push only ever changes columns to the right of the one it is working on, so the
+// rewrite of an alignment can be cut at any column k that no earlier step has touched when
+// its turn comes ("clean"): steps >= k then see exactly the input.  Whether k is clean is
+// only known to the run that arrives there, so every chunk starts cold at a column chosen
+// from the input alone (three matches in a row, the last two with different bases: a gap in
+// flight rarely gets through those) and the chunk in front of it checks, at its end, that it
+// has not written past it.  By induction from chunk 0 all chunks are then exact.  A chunk
+// that did write past its end is run again with the next chunk taken in (its output goes to
+// the re-run region), and the swallowed chunk's own result is dropped by k_norm_scan.
+//   k_norm_chunk   lane per chunk: the streaming push loop (dg_norm_run) on [k0, k1)
+//   k_norm_scan    lane per alignment: offsets of the chunks, trimAln (:219-242)
+//   k_norm_finish  lane per chunk: columns to their final place; what dg_finish_alignment
+//                  does, on the chunk's share of the trimmed window
+// ---------------------------------------------------------------------------
+#define DG_NCH 1024u           // input columns per window
+#define DG_CH_NONE 0xFFFFFFFFu
 
-    uint32_t ip = 0, e = 0, i = 0, w = 0, jt = 0, jq = 0;
-    bool in_done = (len == 0), overflow = false;
+__device__ __forceinline__ bool dg_match_col(uint8_t qb, uint8_t tb) { return qb == tb && qb != DG_GAP && qb != '.'; }
+
+// column a chunk starts at inside window c of the alignment, DG_CH_NONE if there is none
+__device__ inline uint32_t dg_chunk_start(const uint8_t *q, const uint8_t *t, uint32_t len, uint32_t c) {
+    if (c == 0) return 0;
+    const uint64_t w0 = (uint64_t)c * DG_NCH;
+    if (w0 >= len) return DG_CH_NONE;
+    const uint32_t hi = (uint64_t)len < w0 + DG_NCH ? len : (uint32_t)(w0 + DG_NCH);
+    for (uint32_t k = (uint32_t)w0; k < hi; k++) {
+        const uint8_t b = q[k];
+        if (dg_match_col(b, t[k]) && b != q[k - 1] && dg_match_col(q[k - 1], t[k - 1]) && dg_match_col(q[k - 2], t[k - 2]))
+            return k;
+    }
+    return DG_CH_NONE;
+}
+
+struct DgChunkRun { uint32_t w, tb; bool dirty, overflow; };
+
+// normalizeGaps (Alignment.cpp:142-214) on the input columns [k0, k1) of an alignment, started
+// cold; the look-ahead may read (and, reported as `dirty`, write) beyond k1.
+__device__ inline DgChunkRun dg_norm_run(const uint8_t *q, const uint8_t *t, const uint32_t len, const uint32_t k0,
+                                         const uint32_t k1, uint16_t *win, uint16_t *out) {
+#define DG_W(x) win[(x) & (DG_NW - 1u)]
+    DgChunkRun r;
+    r.w = 0; r.tb = 0; r.dirty = false; r.overflow = false;
+    if (k0 >= k1) return r;
+    uint32_t ip = k0, e = 0, i = 0, w = 0, tb = 0, jt = 0, jq = 0;
+    uint32_t e_end = 0xFFFFFFFFu;                          // window index of input column k1, once known
+    // finished columns collect in a 128-bit shift register and leave 8 at a time (out is
+    // 16-byte aligned): one store request instead of eight
+    uint32_t o0 = 0, o1 = 0, o2 = 0, o3 = 0;
+    bool in_done = false, dirty = false;
     for (;;) {
         // ---- refill: Alignment.cpp:142-159 on the next (up to) 16 input columns ----
         if (!in_done) {
-            if ((e - i) + 32u > DG_NW) { overflow = true; break; }
+            if ((e - i) + 32u > DG_NW) { r.overflow = true; break; }
             uint32_t take = len - ip;
             if (take > 16u) take = 16u;
+            if (ip < k1 && take > k1 - ip) take = k1 - ip;  // land on the chunk's end exactly
             unsigned long long q0 = 0, q1 = 0, t0 = 0, t1 = 0;
             if (take == 16u && (((uintptr_t)(q + ip)) & 15u) == 0) {
                 const uint4 qv = *reinterpret_cast<const uint4 *>(q + ip);
@@ -185,28 +217,28 @@ __global__ __launch_bounds__(64) void k_normalize(DgParams p) {
                 t0 = (unsigned long long)tv.x | ((unsigned long long)tv.y << 32);
                 t1 = (unsigned long long)tv.z | ((unsigned long long)tv.w << 32);
             } else {
-                // head (up to the next 16-byte boundary) and tail: byte loads
                 const uint32_t to_align = (uint32_t)((16u - (((uintptr_t)(q + ip)) & 15u)) & 15u);
                 if (to_align && take > to_align) take = to_align;
                 for (uint32_t k = 0; k < take; k++) {
-                    const unsigned long long qb = q[ip + k], tb = t[ip + k];
-                    if (k < 8) { q0 |= qb << (8 * k); t0 |= tb << (8 * k); }
-                    else { q1 |= qb << (8 * (k - 8)); t1 |= tb << (8 * (k - 8)); }
+                    const unsigned long long qb = q[ip + k], tbb = t[ip + k];
+                    if (k < 8) { q0 |= qb << (8 * k); t0 |= tbb << (8 * k); }
+                    else { q1 |= qb << (8 * (k - 8)); t1 |= tbb << (8 * (k - 8)); }
                 }
             }
             for (uint32_t k = 0; k < take; k++) {
                 uint8_t qb = (uint8_t)((k < 8 ? q0 >> (8 * k) : q1 >> (8 * (k - 8))) & 0xffu);
-                uint8_t tb = (uint8_t)((k < 8 ? t0 >> (8 * k) : t1 >> (8 * (k - 8))) & 0xffu);
+                uint8_t tbb = (uint8_t)((k < 8 ? t0 >> (8 * k) : t1 >> (8 * (k - 8))) & 0xffu);
                 if (qb == '.') qb = DG_GAP;
-                if (tb == '.') tb = DG_GAP;
-                if (qb != tb && qb != DG_GAP && tb != DG_GAP) {
-                    DG_W(e) = DG_COL(DG_GAP, tb); e++;
+                if (tbb == '.') tbb = DG_GAP;
+                if (qb != tbb && qb != DG_GAP && tbb != DG_GAP) {
+                    DG_W(e) = DG_COL(DG_GAP, tbb); e++;
                     DG_W(e) = DG_COL(qb, DG_GAP); e++;
                 } else {
-                    DG_W(e) = DG_COL(qb, tb); e++;
+                    DG_W(e) = DG_COL(qb, tbb); e++;
                 }
             }
             ip += take;
+            if (ip == k1) e_end = e;
             if (ip == len) in_done = true;
         }
         // ---- Alignment.cpp:165-198 push gaps to the right, as far as the window reaches.
@@ -214,8 +246,8 @@ __global__ __launch_bounds__(64) void k_normalize(DgParams p) {
         // a base).  A step that runs out of window stores what it has done to column i
         // and is restarted after the refill: the t-pass of a restarted step either finds
         // its column already filled or repeats the same fruitless look-up. ----
-        while (i < e) {
-            if (i + 1 == e && !in_done) break;            // not known yet whether i is the last column
+        while (i < e && i < e_end) {
+            if (i + 1 == e && !in_done) break;
             const uint16_t c = DG_W(i);
             uint8_t qi = DG_Q(c), ti = DG_T(c);
             bool more = false;
@@ -225,7 +257,7 @@ __global__ __launch_bounds__(64) void k_normalize(DgParams p) {
                     while (jt < e && DG_T(DG_W(jt)) == DG_GAP) jt++;
                     if (jt < e) {
                         const uint16_t cj = DG_W(jt);
-                        if (DG_T(cj) == qi) { ti = qi; DG_W(jt) = DG_COL(DG_Q(cj), DG_GAP); }
+                        if (DG_T(cj) == qi) { ti = qi; DG_W(jt) = DG_COL(DG_Q(cj), DG_GAP); dirty |= jt >= e_end; }
                     } else if (!in_done) more = true;
                 }
                 if (!more && qi == DG_GAP) {
@@ -233,19 +265,224 @@ __global__ __launch_bounds__(64) void k_normalize(DgParams p) {
                     while (jq < e && DG_Q(DG_W(jq)) == DG_GAP) jq++;
                     if (jq < e) {
                         const uint16_t cj = DG_W(jq);
-                        if (DG_Q(cj) == ti) { qi = ti; DG_W(jq) = DG_COL(DG_GAP, DG_T(cj)); }
+                        if (DG_Q(cj) == ti) { qi = ti; DG_W(jq) = DG_COL(DG_GAP, DG_T(cj)); dirty |= jq >= e_end; }
                     } else if (!in_done) more = true;
                 }
             }
             if (more) { DG_W(i) = DG_COL(qi, ti); break; }
-            if (qi != DG_GAP || ti != DG_GAP) buf[w++] = DG_COL(qi, ti);   // :209-214
+            if (qi != DG_GAP || ti != DG_GAP) {                                // :209-214
+                o0 = (o0 >> 16) | (o1 << 16); o1 = (o1 >> 16) | (o2 << 16); o2 = (o2 >> 16) | (o3 << 16);
+                o3 = (o3 >> 16) | ((uint32_t)DG_COL(qi, ti) << 16);
+                w++;
+                tb += (ti != DG_GAP);
+                if ((w & 7u) == 0) *reinterpret_cast<uint4 *>(out + w - 8) = make_uint4(o0, o1, o2, o3);
+            }
             i++;
         }
-        if (in_done && i == e) break;
+        if (i == e_end) break;
     }
 #undef DG_W
-    if (overflow) { p.n_hi[a] = DG_REDO; return; }
-    dg_finish_alignment(p, a, buf, w);
+    // the last, partial group: its columns sit at the top of the register
+    for (uint32_t k = w & 7u, x = w - (w & 7u); k > 0; k--, x++) {
+        const uint32_t sh = 8u - k;                        // column x is sh places from the bottom
+        const uint32_t word = sh >> 1;
+        const uint32_t v = word == 0 ? o0 : word == 1 ? o1 : word == 2 ? o2 : o3;
+        out[x] = (uint16_t)((sh & 1u) ? v >> 16 : v & 0xffffu);
+    }
+    r.w = w; r.tb = tb; r.dirty = dirty;
+    return r;
+}
+
+__global__ __launch_bounds__(64) void k_norm_chunk(DgParams p) {
+    __shared__ uint16_t s_win[64 * DG_NW_STRIDE];
+    // neighbouring chunks are ~1 KB of input (4 KB of scratch) apart: lanes of a wave take chunks
+    // a whole grid apart instead, or their lines fight for the same few L1 sets and L2 channels
+    const uint32_t g = threadIdx.x * gridDim.x + blockIdx.x;
+    if (g >= p.n_chunks) return;
+    if (dg_failed(p)) return;
+    const uint32_t a = p.ch_aln[g];
+    const uint32_t c = g - p.ch_base[a], nwin = p.ch_base[a + 1] - p.ch_base[a];
+    const uint64_t off = p.aln_off[a];
+    const uint32_t len = p.aln_len[a];
+    const uint8_t *q = p.q + off, *t = p.t + off;
+    uint32_t flag = 0;
+    DgChunkRun r;
+    r.w = 0; r.tb = 0; r.dirty = false; r.overflow = false;
+    uint32_t k0 = DG_CH_NONE, cn = c + 1;
+    uint64_t src = 0;
+    if (p.flags & DG_F_RAW) {                              // raw columns: the slow kernel copies them
+        if (c == 0) { k0 = 0; cn = nwin; flag = 1; }
+    } else {
+        k0 = dg_chunk_start(q, t, len, c);
+        if (k0 != DG_CH_NONE) {
+            uint16_t *win = s_win + threadIdx.x * DG_NW_STRIDE;
+            src = (2ull * (off + k0) + 8ull * g + 7ull) & ~7ull;     // 16-byte aligned, regions stay disjoint
+            for (;;) {
+                uint32_t k1 = len;
+                for (; cn < nwin; cn++) {
+                    const uint32_t s = dg_chunk_start(q, t, len, cn);
+                    if (s != DG_CH_NONE) { k1 = s; break; }
+                }
+                r = dg_norm_run(q, t, len, k0, k1, win, p.norm_tmp + src);
+                if (r.overflow) { flag = 1; break; }
+                if (!r.dirty) break;
+                // a gap in flight got past the end: once more with the next chunk taken in,
+                // into a stretch of the re-run region
+                cn++;
+                uint32_t k2 = len;
+                for (uint32_t x = cn; x < nwin; x++) {
+                    const uint32_t s = dg_chunk_start(q, t, len, x);
+                    if (s != DG_CH_NONE) { k2 = s; break; }
+                }
+                const unsigned long long need = (2ull * (k2 - k0) + 15ull) & ~7ull;
+                const unsigned long long o = atomicAdd(&p.st->ovf_top, need);
+                if (p.tmp_main + o + need > p.tmp_cap) { flag = 1; break; }      // out of room: slow path
+                src = p.tmp_main + o;
+            }
+        }
+    }
+    p.ch_k0[g] = k0; p.ch_next[g] = cn; p.ch_w[g] = r.w; p.ch_tb[g] = r.tb;
+    p.ch_flag[g] = flag; p.ch_src[g] = src;
+}
+
+__global__ __launch_bounds__(64) void k_norm_scan(DgParams p) {
+    const uint32_t a = blockIdx.x * 64 + threadIdx.x;
+    if (a >= p.A) return;
+    if (dg_failed(p)) return;
+    const uint32_t g0 = p.ch_base[a], g1 = p.ch_base[a + 1];
+    bool redo = false;
+    uint32_t m = 0, tbt = 0;
+    for (uint32_t g = g0; g < g1;) {
+        if (p.ch_k0[g] == DG_CH_NONE) { p.ch_out[g] = DG_CH_NONE; g++; continue; }
+        redo |= p.ch_flag[g] != 0;
+        p.ch_out[g] = m; p.ch_adv[g] = tbt;
+        m += p.ch_w[g]; tbt += p.ch_tb[g];
+        uint32_t nx = g0 + p.ch_next[g];
+        if (nx > g1) nx = g1;
+        for (uint32_t x = g + 1; x < nx; x++) p.ch_out[x] = DG_CH_NONE;       // empty or swallowed windows
+        g = nx;
+    }
+    if (redo) { p.n_hi[a] = DG_REDO; return; }
+    // Alignment.cpp:219-242 trimAln: whole chunks by their counts, the last one column by column
+    const uint32_t trim = p.trim;
+    uint32_t lbases = 0, rbases = 0, lo = 0, hi = m;
+    for (uint32_t g = g0; g < g1 && lbases < trim && lo < m; g++) {
+        if (p.ch_out[g] == DG_CH_NONE) continue;
+        const uint32_t w = p.ch_w[g], tb = p.ch_tb[g];
+        if (lbases + tb < trim) { lo += w; lbases += tb; continue; }
+        const uint16_t *src = p.norm_tmp + p.ch_src[g];
+        for (uint32_t x = 0; x < w && lbases < trim; x++) {
+            if (DG_T(src[x]) != DG_GAP) lbases++;
+            lo++;
+        }
+    }
+    for (uint32_t g = g1; g > g0 && rbases < trim && hi > lo;) {
+        g--;
+        const uint32_t o = p.ch_out[g];
+        if (o == DG_CH_NONE) continue;
+        const uint32_t tb = p.ch_tb[g];
+        if (o >= lo && rbases + tb < trim) { hi = o; rbases += tb; continue; }
+        const uint16_t *src = p.norm_tmp + p.ch_src[g];
+        while (rbases < trim && hi > lo && hi > o) {
+            if (DG_T(src[--hi - o]) != DG_GAP) rbases++;
+        }
+    }
+    p.n_lo[a] = lo; p.n_hi[a] = hi; p.n_start[a] = p.aln_start[a] + lbases; p.n_lb[a] = lbases;
+    p.n_ins[a] = 0; p.n_del[a] = 0;
+    atomicAdd(&p.st->n_columns, (unsigned long long)(hi - lo));
+}
+
+// 8 columns starting h columns into the 16 columns (A, B)
+__device__ __forceinline__ uint4 dg_funnel_cols(const uint4 A, const uint4 B, const uint32_t h) {
+    const bool w1 = (h >> 1) & 1u, w2 = (h >> 2) & 1u, half = h & 1u;
+    const uint32_t u0 = w1 ? A.y : A.x, u1 = w1 ? A.z : A.y, u2 = w1 ? A.w : A.z, u3 = w1 ? B.x : A.w,
+                   u4 = w1 ? B.y : B.x, u5 = w1 ? B.z : B.y, u6 = w1 ? B.w : B.z;
+    const uint32_t t0 = w2 ? u2 : u0, t1 = w2 ? u3 : u1, t2 = w2 ? u4 : u2, t3 = w2 ? u5 : u3, t4 = w2 ? u6 : u4;
+    uint4 r;
+    r.x = half ? __builtin_amdgcn_alignbit(t1, t0, 16) : t0;
+    r.y = half ? __builtin_amdgcn_alignbit(t2, t1, 16) : t1;
+    r.z = half ? __builtin_amdgcn_alignbit(t3, t2, 16) : t2;
+    r.w = half ? __builtin_amdgcn_alignbit(t4, t3, 16) : t3;
+    return r;
+}
+
+__global__ __launch_bounds__(64) void k_norm_finish(DgParams p) {
+    // neighbouring chunks are ~1 KB of input (4 KB of scratch) apart: lanes of a wave take chunks
+    // a whole grid apart instead, or their lines fight for the same few L1 sets and L2 channels
+    const uint32_t g = threadIdx.x * gridDim.x + blockIdx.x;
+    if (g >= p.n_chunks) return;
+    if (dg_failed(p)) return;
+    const uint32_t o = p.ch_out[g];
+    if (o == DG_CH_NONE) return;
+    const uint32_t a = p.ch_aln[g];
+    const uint32_t hi = p.n_hi[a];
+    if (hi == DG_REDO) return;
+    const uint32_t lo = p.n_lo[a], start = p.n_start[a], lb = p.n_lb[a];
+    const uint32_t w = p.ch_w[g], adv0 = p.ch_adv[g];
+    const uint16_t *src = p.norm_tmp + p.ch_src[g];                  // 16-byte aligned
+    const uint4 *src4 = reinterpret_cast<const uint4 *>(src);
+    uint16_t *dst = p.norm + p.norm_off[a] + o;                       // norm_off is a multiple of 8 columns
+    // what addAln will do with the window (see dg_finish_alignment)
+    const bool graph = !(p.flags & DG_F_A1_ONLY);
+    uint32_t t_idx = 0, r = 0, K = 0;
+    uint32_t *Cm = nullptr;
+    if (graph) {
+        t_idx = p.aln_tgt[a];
+        if (p.tactive[t_idx]) {
+            const uint64_t ab = p.aln_begin[t_idx];
+            r = (uint32_t)(a - ab);
+            K = (uint32_t)(p.aln_begin[t_idx + 1] - ab);
+            Cm = p.matC + p.mat_base[t_idx];
+        }
+    }
+    const uint32_t tlen = graph ? p.tlen[t_idx] : 0xFFFFFFFFu;
+    // target bases between the trimmed start and this chunk (a chunk in front of lo has none)
+    uint32_t adv = adv0 > lb ? adv0 - lb : 0u;
+    uint32_t n_ins = 0, n_del = 0, run = 0;
+    bool conf = start >= 1 && !((uint64_t)start - 1 + adv > (uint64_t)tlen && adv > 0);
+    // the chunk's share of the trimmed window, as chunk-relative column numbers
+    const uint32_t f0 = lo > o ? lo - o : 0u;
+    const uint32_t f1 = hi > o ? (hi - o < w ? hi - o : w) : 0u;
+    const bool any = f1 > f0;
+    const uint32_t fspan = any ? f1 - f0 : 0u;
+
+    // columns go to their final place as aligned 16-byte stores: h single columns up to the
+    // destination's next 16-byte line, then blocks funnelled out of two source vectors
+    const uint32_t h0 = (8u - (o & 7u)) & 7u;
+    const uint32_t h = h0 < w ? h0 : w;
+    const uint32_t nb = (w - h) / 8u;
+    for (uint32_t x = 0; x < h; x++) dst[x] = src[x];
+    uint4 *dst4 = reinterpret_cast<uint4 *>(dst + h);
+    const uint32_t nvec = (w + 7u) / 8u;
+    uint4 prev = make_uint4(0, 0, 0, 0);
+    for (uint32_t v = 0; v < nvec; v++) {
+        const uint4 cur = src4[v];
+        if (v >= 1 && v - 1 < nb) dst4[v - 1] = dg_funnel_cols(prev, cur, h);
+        prev = cur;
+        if (8u * v + 8u <= f0 || 8u * v >= f1) continue;         // nothing of the window in this vector
+        const uint32_t w4[4] = {cur.x, cur.y, cur.z, cur.w};
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const uint16_t c = (uint16_t)((k & 1) ? w4[k >> 1] >> 16 : w4[k >> 1] & 0xffffu);
+            if (8u * v + (uint32_t)k - f0 >= fspan) continue;
+            const uint8_t qb = DG_Q(c), tb = DG_T(c);
+            if (qb == tb || qb == DG_GAP) {
+                if (run) { if (Cm && conf && start + adv <= tlen + 1) Cm[(uint64_t)(start + adv) * K + r] = run; run = 0; }
+                adv++; n_del += (qb != tb);
+                if ((uint64_t)start - 1 + adv > (uint64_t)tlen) conf = false;
+            } else if (tb == DG_GAP) { n_ins++; run++; }
+        }
+    }
+    if (nvec >= 1 && nb == nvec) dst4[nb - 1] = dg_funnel_cols(prev, make_uint4(0, 0, 0, 0), h);   // h == 0, w % 8 == 0
+    for (uint32_t x = h + 8u * nb; x < w; x++) dst[x] = src[x];
+    // the column after the chunk is a match (the next chunk's first) or the end of the window
+    if (run && Cm && conf && start + adv <= tlen + 1) Cm[(uint64_t)(start + adv) * K + r] = run;
+    if (n_ins) atomicAdd(&p.n_ins[a], n_ins);
+    if (n_del) atomicAdd(&p.n_del[a], n_del);
+    if (graph && any && !conf) {
+        dg_fail(p, DG_E_NONCONF);
+        p.st->bad_aln = a;
+    }
 }
 
 // The same algorithm with the whole expanded alignment in HBM: raw mode and

@@ -347,6 +347,45 @@ def test_long_gap_runs_take_the_redo_path(gpu_ctx_factory):
         assert (gq, gt, gs) == oracle.trim_aln(qn, tn, s, 7)
 
 
+def test_chunked_normalize_boundaries(gpu_ctx_factory):
+    """normalizeGaps runs in chunks of ~1024 input columns that start cold (k_norm_chunk).
+    Gaps in flight across chunk starts: an insertion in front of a long dinucleotide repeat
+    slides through every chunk start inside it (the chunk in front is run again with the next
+    one taken in), small alphabets keep many gaps moving, and trimAln's window ends inside,
+    at and across chunk edges."""
+    rng = np.random.default_rng(77)
+    alns = []
+    # (AC)^n backbone stretch with an 'AC' / 'A' / 'CA' insertion in front of it, at several phases
+    for ins, at, rep_len in [(b"AC", 1000, 2600), (b"A", 1020, 1500), (b"CACA", 2040, 3000), (b"AC", 30, 5000)]:
+        left = bytes(b"ACGT"[j] for j in rng.integers(0, 4, at))
+        right = bytes(b"ACGT"[j] for j in rng.integers(0, 4, 700))
+        rep = b"AC" * (rep_len // 2)
+        t = left + b"G" + b"-" * len(ins) + rep + b"T" + right
+        q = left + b"G" + ins + rep + b"T" + right
+        alns.append((1, q, t))
+        # the same with a deletion in the query instead (gaps in the other string)
+        alns.append((1, left + b"G" + b"-" * len(ins) + rep + b"T" + right, left + b"G" + ins + rep + b"T" + right))
+    # long random alignments over 2- and 4-letter alphabets, high indel rates
+    for i in range(24):
+        alph = [b"AC", b"ACGT", b"A"][i % 3]
+        tl = int(rng.integers(1500, 6000))
+        a1, _ = random_target(rng, tl, 1, alphabet=alph, sub=0.05, ins=0.15, dele=0.10, ins_ext=0.4, full_span=True,
+                              dots=(i % 5 == 0))
+        alns.append(a1[0])
+    ctx = gpu_ctx_factory(min_cov=0, min_len=0, trim=0, min_weight=0)
+    for trim in (0, 1, 50, 1023, 1024, 1100, 3000):
+        got = ctx.normalize(alns, trim=trim)
+        for (s, q, t), (gs, gq, gt) in zip(alns, got):
+            qn, tn = oracle.normalize_gaps(q, t)
+            assert (gq, gt, gs) == oracle.trim_aln(qn, tn, s, trim), f"trim {trim}"
+    # and through the graph: matC / counts of the chunked finish against the oracle consensus
+    tl = 4000
+    ta, bb = random_target(rng, tl, 12, alphabet=b"AC", sub=0.04, ins=0.12, dele=0.08, ins_ext=0.4, full_span=True)
+    batch = batch_from_targets([(tl, ta, bb)])
+    _check_batch(gpu_ctx_factory, batch, min_cov=0, min_len=0, trim=0, min_weight=0)
+    _check_batch(gpu_ctx_factory, batch, min_cov=4, min_len=100, trim=1030)
+
+
 def test_idempotent_reruns_same_context(gpu_ctx_factory):
     """Same context, same resident batch, run twice: identical output (no state leaks
     between runs, workspace reuse is clean)."""
