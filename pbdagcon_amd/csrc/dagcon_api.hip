@@ -44,6 +44,9 @@ struct Ctx {
     std::vector<uint64_t> h_aln_begin, h_aln_off, h_mat_base, h_bbv_base, h_bb_off;
     std::vector<uint8_t> h_tactive;
     std::vector<uint32_t> h_ch_base, h_ch_aln;      // chunk tables of k_norm_*
+    std::vector<uint32_t> h_ck_base;                // first k_emit checkpoint of each alignment
+    uint64_t n_ckpt = 0;
+    uint32_t emit_shift = 9;                        // 512 backbone positions per k_emit wave
     uint32_t n_chunks = 0;
     uint64_t tmp_main = 0, tmp_cap = 0;
 
@@ -52,7 +55,7 @@ struct Ctx {
         d_bb, d_bb_off, d_mat_base, d_bbv_base;
     DevBuf d_nmis, d_norm_off, d_n_lo, d_n_hi, d_n_start, d_n_ins, d_n_del, d_norm;
     DevBuf d_ch_aln, d_ch_base, d_ch_k0, d_ch_next, d_ch_w, d_ch_tb, d_ch_flag, d_ch_src, d_ch_out, d_ch_adv,
-        d_n_lb, d_norm_tmp;
+        d_n_lb, d_norm_tmp, d_ckpt, d_ck_base;
     DevBuf d_node_base, d_n_nodes, d_pool_base, d_pool_size, d_pool_top, d_t_nins;
     DevBuf d_matA, d_matD, d_matC, d_cov, d_gcount, d_gbase, d_bid;
     DevBuf d_nodes, d_best, d_queue, d_score, d_cns_tmp;
@@ -176,6 +179,7 @@ void fill_params(Ctx *c, DgParams &p) {
     p.ch_out = (uint32_t *)c->d_ch_out.p; p.ch_adv = (uint32_t *)c->d_ch_adv.p;
     p.n_lb = (uint32_t *)c->d_n_lb.p; p.norm_tmp = (uint16_t *)c->d_norm_tmp.p;
     p.tmp_main = c->tmp_main; p.tmp_cap = c->tmp_cap;
+    p.ckpt = (uint32_t *)c->d_ckpt.p; p.ck_base = (const uint32_t *)c->d_ck_base.p; p.emit_shift = c->emit_shift;
     p.node_base = (uint64_t *)c->d_node_base.p; p.n_nodes = (uint32_t *)c->d_n_nodes.p;
     p.pool_base = (uint64_t *)c->d_pool_base.p; p.pool_size = (uint32_t *)c->d_pool_size.p;
     p.pool_top = (uint32_t *)c->d_pool_top.p; p.t_nins = (uint32_t *)c->d_t_nins.p;
@@ -203,6 +207,7 @@ void fill_params(Ctx *c, DgParams &p) {
 void launch_normalize(Ctx *c, const DgParams &p) {
     hipStream_t s = c->stream;
     if (c->A == 0) return;
+    (void)hipMemsetAsync(c->d_ckpt.p, 0xFF, c->n_ckpt * 4, s);
     hipLaunchKernelGGL(k_count, dim3(c->A), dim3(256), 0, s, p);
     hipLaunchKernelGGL(k_norm_chunk, dim3((c->n_chunks + 63) / 64), dim3(64), 0, s, p);
     hipLaunchKernelGGL(k_norm_scan, dim3((c->A + 63) / 64), dim3(64), 0, s, p);
@@ -233,7 +238,9 @@ int launch_all(Ctx *c) {
         hipLaunchKernelGGL(k_groups, dim3(c->T, rows4), dim3(256), 0, s, p);
         hipLaunchKernelGGL(k_gscan, dim3(c->T), dim3(1024), 0, s, p);
         hipLaunchKernelGGL(k_init_nodes, dim3(c->T, (c->max_tlen + 2 + 255) / 256), dim3(256), 0, s, p);
-        if (c->A > 0) hipLaunchKernelGGL(k_emit, dim3(c->T, (c->max_k + DG_ERPW - 1) / DG_ERPW), dim3(64), 0, s, p);
+        if (c->A > 0)
+            hipLaunchKernelGGL(k_emit, dim3(c->T, (c->max_k + DG_ERPW - 1) / DG_ERPW, ((c->max_tlen + 2) >> c->emit_shift) + 1),
+                               dim3(64), 0, s, p);
         const size_t lds = (size_t)4 * 2 * (c->max_k + 2) * sizeof(int32_t);
         if (lds > 65536)
             HIPCHK(c, hipFuncSetAttribute((const void *)k_lists, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -281,6 +288,10 @@ int dagcon_create(const dagcon_opts *opts, dagcon_ctx **out) {
     Ctx *c = new Ctx();
     c->opts = *opts;
     c->device = opts->device;
+    if (const char *e = getenv("DAGCON_EMIT_SHIFT")) {      // test knob: k_emit stretches of 1 << v positions
+        const int v = atoi(e);
+        if (v >= 4 && v <= 20) c->emit_shift = (uint32_t)v;
+    }
     if (const char *e = getenv("DAGCON_MERGE_SEGS")) {      // tuning knob: 1 = one worker per target
         const int v = atoi(e);
         if (v >= 1 && v <= 64) c->seg_env = (uint32_t)v;
@@ -305,7 +316,7 @@ void dagcon_destroy(dagcon_ctx *ctx) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     DevBuf *all[] = {&c->d_q, &c->d_t, &c->d_aln_off, &c->d_aln_len, &c->d_aln_start, &c->d_aln_tgt,
                      &c->d_tlen, &c->d_aln_begin, &c->d_tactive, &c->d_bb, &c->d_bb_off, &c->d_mat_base,
-                     &c->d_bbv_base, &c->d_nmis, &c->d_norm_off, &c->d_n_lo, &c->d_n_hi, &c->d_n_start, &c->d_ch_aln, &c->d_ch_base, &c->d_ch_k0, &c->d_ch_next, &c->d_ch_w, &c->d_ch_tb, &c->d_ch_flag, &c->d_ch_src, &c->d_ch_out, &c->d_ch_adv, &c->d_n_lb, &c->d_norm_tmp,
+                     &c->d_bbv_base, &c->d_nmis, &c->d_norm_off, &c->d_n_lo, &c->d_n_hi, &c->d_n_start, &c->d_ch_aln, &c->d_ch_base, &c->d_ch_k0, &c->d_ch_next, &c->d_ch_w, &c->d_ch_tb, &c->d_ch_flag, &c->d_ch_src, &c->d_ch_out, &c->d_ch_adv, &c->d_n_lb, &c->d_norm_tmp, &c->d_ckpt, &c->d_ck_base,
                      &c->d_n_ins, &c->d_n_del, &c->d_norm, &c->d_node_base, &c->d_n_nodes,
                      &c->d_pool_base, &c->d_pool_size, &c->d_pool_top, &c->d_t_nins, &c->d_matA, &c->d_matD,
                      &c->d_matC, &c->d_cov, &c->d_gcount, &c->d_gbase, &c->d_bid, &c->d_nodes,
@@ -398,6 +409,13 @@ int dagcon_upload(dagcon_ctx *ctx, const dagcon_batch *b) {
         if (c->h_ch_aln.size() + nw > 0xFFFFFFF0ull) return fail(c, DAGCON_ERR_UNSUPPORTED, "too many alignment columns");
         c->h_ch_aln.insert(c->h_ch_aln.end(), nw, a);
     }
+    c->h_ck_base.assign((size_t)c->A, 0);
+    c->n_ckpt = 0;
+    for (uint32_t a = 0; a < c->A; a++) {
+        c->h_ck_base[a] = (uint32_t)c->n_ckpt;
+        c->n_ckpt += (((uint64_t)c->h_tlen[c->h_aln_tgt[a]] + 2) >> c->emit_shift) + 1;
+        if (c->n_ckpt > 0xFFFFFFF0ull) return fail(c, DAGCON_ERR_UNSUPPORTED, "too many alignment columns");
+    }
     c->h_ch_base[c->A] = (uint32_t)c->h_ch_aln.size();
     c->n_chunks = (uint32_t)c->h_ch_aln.size();
     c->tmp_main = (2ull * b->blob_bytes + 8ull * c->n_chunks + 15ull) & ~7ull;
@@ -427,6 +445,8 @@ int dagcon_upload(dagcon_ctx *ctx, const dagcon_batch *b) {
     if ((r = upload_vec(c, c->d_bbv_base, c->h_bbv_base))) return r;
     if ((r = upload_vec(c, c->d_ch_base, c->h_ch_base))) return r;
     if ((r = upload_vec(c, c->d_ch_aln, c->h_ch_aln))) return r;
+    if ((r = upload_vec(c, c->d_ck_base, c->h_ck_base))) return r;
+    ENSURE(c, c->d_ckpt, c->n_ckpt * 4);
 
     // work arrays whose size the host knows
     const size_t A4 = (size_t)c->A * 4, T4 = (size_t)T * 4;

@@ -74,6 +74,8 @@ struct __attribute__((aligned(16))) DgNode {
 #define DG_CELL_DEL     0x1FFFFFFu
 #define DG_CELL_BASE(c) ((uint8_t)((c) >> 25))
 #define DG_MAX_NODES    0x1FFFFFDu
+#define DG_EMIT_SEG     512u   // backbone positions per k_emit wave: default of DgParams::emit_shift (1 << 9)
+#define DG_CK_NONE      0xFFFFFFFFu
 
 struct DgParams {
     // ---- inputs (resident in HBM after dagcon_upload) ----
@@ -110,6 +112,11 @@ struct DgParams {
     uint32_t *ch_out, *ch_adv;     // after k_norm_scan: column index / target bases in front, DG_CH_NONE: no chunk
     uint32_t *n_lb;                // [A] target bases trimAln took off the left end
     uint16_t *norm_tmp;            // chunk scratch: 2 columns per input column, then the re-run region
+    // column of alignment a where backbone position s << emit_shift begins (its insertion run first),
+    // at ckpt[ck_base[a] + s]; DG_CK_NONE where the read has no column at that position
+    uint32_t *ckpt;
+    const uint32_t *ck_base;       // [A]
+    uint32_t emit_shift;           // log2 of the positions per k_emit wave (>= 4: whole 16-position batches)
     uint64_t tmp_main, tmp_cap;    // uint16 units: start of the re-run region, end of the scratch
     // ---- per target work arrays ----
     uint64_t *node_base;

@@ -116,28 +116,33 @@ __device__ inline void dg_finish_alignment(const DgParams &p, uint32_t a, uint16
     bool conf = start >= 1;
     uint32_t i = lo;
     // 8 columns per 16-byte load once the index is a multiple of 8 (buffers are 16-byte aligned)
-#define DG_FIN_COL(c)                                                                     \
+#define DG_FIN_COL(c, ci_)                                                                \
     do {                                                                                  \
         const uint8_t qb_ = DG_Q(c), tb_ = DG_T(c);                                       \
         if (qb_ == tb_ || qb_ == DG_GAP) {                                                \
+            if (Cm && conf && ((start + adv) & ((1u << p.emit_shift) - 1u)) == 0 && start + adv <= tlen + 1) \
+                ck[(start + adv) >> p.emit_shift] = ci_ - run;                            \
             if (run) { if (Cm && conf && start + adv <= tlen + 1) Cm[(uint64_t)(start + adv) * K + r] = run; run = 0; } \
             adv++; n_del += (qb_ != tb_);                                                 \
             if ((uint64_t)start - 1 + adv > (uint64_t)tlen) conf = false;                 \
         } else if (tb_ == DG_GAP) { n_ins++; run++; }                                     \
     } while (0)
-    while (i < hi && (i & 7u)) { const uint16_t c = buf[i++]; DG_FIN_COL(c); }
+    uint32_t *ck = p.ckpt + p.ck_base[a];
+    while (i < hi && (i & 7u)) { const uint16_t c = buf[i]; DG_FIN_COL(c, i); i++; }
     while (i + 8 <= hi) {
         const uint4 v = *reinterpret_cast<const uint4 *>(buf + i);
         const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const uint16_t c0 = (uint16_t)(w4[k] & 0xffffu), c1 = (uint16_t)(w4[k] >> 16);
-            DG_FIN_COL(c0);
-            DG_FIN_COL(c1);
+            DG_FIN_COL(c0, i + 2 * k);
+            DG_FIN_COL(c1, i + 2 * k + 1);
         }
         i += 8;
     }
-    while (i < hi) { const uint16_t c = buf[i++]; DG_FIN_COL(c); }
+    while (i < hi) { const uint16_t c = buf[i]; DG_FIN_COL(c, i); i++; }
+    if (run && Cm && conf && ((start + adv) & ((1u << p.emit_shift) - 1u)) == 0 && start + adv <= tlen + 1)
+        ck[(start + adv) >> p.emit_shift] = hi - run;     // a trailing insertion run: the position after the read's last
     if (run && Cm && conf && start + adv <= tlen + 1) Cm[(uint64_t)(start + adv) * K + r] = run;
 #undef DG_FIN_COL
     p.n_lo[a] = lo; p.n_hi[a] = hi; p.n_start[a] = start;
@@ -436,6 +441,8 @@ __global__ __launch_bounds__(64) void k_norm_finish(DgParams p) {
         }
     }
     const uint32_t tlen = graph ? p.tlen[t_idx] : 0xFFFFFFFFu;
+    uint32_t *ck = p.ckpt + p.ck_base[a];
+    const uint32_t ck_mask = (1u << p.emit_shift) - 1u;
     // target bases between the trimmed start and this chunk (a chunk in front of lo has none)
     uint32_t adv = adv0 > lb ? adv0 - lb : 0u;
     uint32_t n_ins = 0, n_del = 0, run = 0;
@@ -467,6 +474,10 @@ __global__ __launch_bounds__(64) void k_norm_finish(DgParams p) {
             if (8u * v + (uint32_t)k - f0 >= fspan) continue;
             const uint8_t qb = DG_Q(c), tb = DG_T(c);
             if (qb == tb || qb == DG_GAP) {
+                // (the first column of a chunk inside the window: the chunk in front records it,
+                // it may end in the insertion run that belongs to this position)
+                if (Cm && conf && ((start + adv) & ck_mask) == 0 && start + adv <= tlen + 1 && !(8u * v + (uint32_t)k == 0 && o > lo))
+                    ck[(start + adv) >> p.emit_shift] = o + 8u * v + (uint32_t)k - run;
                 if (run) { if (Cm && conf && start + adv <= tlen + 1) Cm[(uint64_t)(start + adv) * K + r] = run; run = 0; }
                 adv++; n_del += (qb != tb);
                 if ((uint64_t)start - 1 + adv > (uint64_t)tlen) conf = false;
@@ -475,7 +486,10 @@ __global__ __launch_bounds__(64) void k_norm_finish(DgParams p) {
     }
     if (nvec >= 1 && nb == nvec) dst4[nb - 1] = dg_funnel_cols(prev, make_uint4(0, 0, 0, 0), h);   // h == 0, w % 8 == 0
     for (uint32_t x = h + 8u * nb; x < w; x++) dst[x] = src[x];
-    // the column after the chunk is a match (the next chunk's first) or the end of the window
+    // the column after the chunk is a match (the next chunk's first) or the end of the window;
+    // a trailing insertion run of the read belongs to the position after its last one
+    if (any && Cm && conf && ((start + adv) & ck_mask) == 0 && start + adv <= tlen + 1 && (o + f1 < hi || run))
+        ck[(start + adv) >> p.emit_shift] = o + f1 - run;
     if (run && Cm && conf && start + adv <= tlen + 1) Cm[(uint64_t)(start + adv) * K + r] = run;
     if (n_ins) atomicAdd(&p.n_ins[a], n_ins);
     if (n_del) atomicAdd(&p.n_del[a], n_del);
@@ -710,7 +724,14 @@ __global__ __launch_bounds__(256) void k_init_nodes(DgParams p) {
 }
 
 // ---------------------------------------------------------------------------
-// k_emit: addAln.  One wave per (target, group of 64 reads), one lane per read.
+// k_emit: addAln.  One wave per (target, group of 64 reads, stretch of 1 << emit_shift
+// backbone positions), one lane per read.
+//
+// A lane enters its stretch at the column k_norm_finish recorded for the stretch's first
+// position (or at the read's start) and finds the vertex in front of it by looking back
+// over the deletion columns; it writes the arrival side of every vertex of the stretch and
+// the departure side of every vertex it created (`own`): for the last one it looks ahead,
+// past the stretch's end, for the vertex the read goes to next.
 //
 // The lanes walk the backbone in lock step, 16 positions per batch.  In a batch a
 // lane first emits the insertion columns in front of a position and then its match
@@ -744,6 +765,7 @@ __global__ __launch_bounds__(64) void k_emit(DgParams p) {
     const uint32_t a = (uint32_t)(ab + (done ? 0 : r));
     const uint32_t blen = p.tlen[t];
     const uint32_t exitpos = blen + 1;
+    if ((blockIdx.z << p.emit_shift) > exitpos) return;      // the grid is sized for the longest target
     const uint64_t nb = p.node_base[t];
     const uint64_t bv = p.bbv_base[t];
     const uint32_t *bid = p.bid + bv, *gbase = p.gbase + bv;
@@ -757,7 +779,36 @@ __global__ __launch_bounds__(64) void k_emit(DgParams p) {
     uint32_t prev = 0;            // vertex id of the previous vertex on the read's path
     uint32_t prev_pos = 0;        // its backbone position (_bbMap for an inserted vertex)
     bool prev_bb = true;
+    bool own = true;              // prev was created by this wave (the enter vertex: by the read's first stretch)
     uint32_t i = lo;
+    const uint32_t P0 = blockIdx.z << p.emit_shift, P1 = P0 + (1u << p.emit_shift);
+    if (!done) {
+        if (bbpos >= P1) done = true;                       // the read starts in a later stretch
+        else if (bbpos < P0) {
+            const uint32_t ck = p.ckpt[p.ck_base[a] + blockIdx.z];
+            if (ck == DG_CK_NONE || ck >= hi) done = true;  // the read ended in an earlier stretch
+            else {
+                i = ck; bbpos = P0; own = false;
+                // the vertex in front: back over deletion columns (and columns addAln skips)
+                uint32_t x = ck, d = 0;
+                while (x > lo) {
+                    const uint16_t c = buf[--x];
+                    const uint8_t qb = DG_Q(c), tb = DG_T(c);
+                    if (qb == tb) { prev_pos = P0 - 1u - d; prev = bid[prev_pos]; break; }
+                    if (qb == DG_GAP) { d++; continue; }
+                    if (tb == DG_GAP) {                     // last vertex of the insertion run of position P0 - d
+                        prev_pos = P0 - d;
+                        const uint32_t c0 = Cm[(uint64_t)prev_pos * K + r];
+                        const uint32_t c1 = r + 1 < K ? Cm[(uint64_t)prev_pos * K + r + 1] : p.gcount[bv + prev_pos];
+                        prev = gbase[prev_pos] + c1 - 1u;
+                        (void)c0;
+                        prev_bb = false;
+                        break;
+                    }
+                }
+            }
+        }
+    }
     uint32_t c_base = 0x80000000u;                // first column staged in colw[] (nothing yet)
     // columns [c_base, c_base + DG_ECOLS) of the lane sit in LDS; a batch normally needs
     // ~18 of them, a long insertion run restages in place
@@ -783,6 +834,7 @@ __global__ __launch_bounds__(64) void k_emit(DgParams p) {
     // among inserted vertices is id - position)
 #define DG_DEPART(NXT)                                                       \
     do {                                                                     \
+        if (!own) break;                                                     \
         if (prev_bb) {                                                       \
             if (prev_pos >= pos0) s_D[(prev_pos - pos0) * 64 + lane] = (NXT) + 1u;   \
             else Dm[(uint64_t)prev_pos * K + r] = (NXT) + 1u;                \
@@ -794,10 +846,10 @@ __global__ __launch_bounds__(64) void k_emit(DgParams p) {
     } while (0)
 
     // first position of the wave (a multiple of 4 below it, for the 16-byte bid loads)
-    uint32_t pos0 = bbpos;
+    uint32_t pos0 = done ? 0xFFFFFFFFu : bbpos;
     for (int o = 32; o > 0; o >>= 1) { const uint32_t x = (uint32_t)__shfl_xor((int)pos0, o); pos0 = x < pos0 ? x : pos0; }
-    pos0 &= ~3u;                                   // bbv_base is a multiple of 4
-    while (!__all(done) && pos0 <= blen + 2u * DG_EB) {   // (every read ends by position tlen + 1)
+    pos0 &= ~3u;                                   // bbv_base is a multiple of 4 (and so is P0 <= pos0)
+    while (!__all(done) && pos0 < P1 && pos0 <= blen + 2u * DG_EB) {   // (every read ends by position tlen + 1)
         // backbone ids of the batch: bid[pos0 .. pos0+15] (reads past tlen+1 stay inside the arena)
         uint32_t bidv[DG_EB];
         {
@@ -829,7 +881,7 @@ __global__ __launch_bounds__(64) void k_emit(DgParams p) {
 #pragma unroll
         for (int j = 0; j < DG_EB; j++) {
             const uint32_t pos = pos0 + j;
-            if (!done && bbpos == pos) {
+            if (!done && bbpos == pos && pos < P1) {
                 // columns in front of this position that do not advance the backbone cursor:
                 // insertions (AlnGraphBoost.cpp:95-104); raw columns that match no branch are skipped
                 uint32_t ins_id = 0;
@@ -851,12 +903,14 @@ __global__ __launch_bounds__(64) void k_emit(DgParams p) {
                         p.nodes[nb + id] = nd;
                         pool[3u * rk + 2u] = prev;
                         DG_DEPART(id);
-                        prev = id; prev_pos = bbpos; prev_bb = false;
+                        prev = id; prev_pos = bbpos; prev_bb = false; own = true;
                     }
                     i++;
                 }
                 if (!have) {                              // :106 the read ends: edge to the exit vertex
-                    exit_cell = true; exit_val = prev + 1u;
+                    // (behind nothing but deletions of this stretch the earlier stretch's look-ahead
+                    // has been here already)
+                    exit_cell = own; exit_val = prev + 1u;
                     const uint32_t ex = bid[exitpos];
                     DG_DEPART(ex);
                     done = true;
@@ -866,7 +920,7 @@ __global__ __launch_bounds__(64) void k_emit(DgParams p) {
                         const uint32_t cur = bidv[j];
                         acell[j] = ((uint32_t)tb << 25) | (prev + 1u);
                         DG_DEPART(cur);
-                        prev = cur; prev_pos = bbpos; prev_bb = true;
+                        prev = cur; prev_pos = bbpos; prev_bb = true; own = true;
                     } else {                              // deletion (:87-93)
                         acell[j] = ((uint32_t)tb << 25) | DG_CELL_DEL;
                     }
@@ -880,14 +934,37 @@ __global__ __launch_bounds__(64) void k_emit(DgParams p) {
 #pragma unroll
             for (int j = 0; j < DG_EB; j++) {
                 const uint32_t pos = pos0 + j;
-                if (pos <= blen) {
+                if (pos <= blen && pos >= P0 && pos < P1) {
                     Am[(uint64_t)pos * K + r] = acell[j];
-                    Dm[(uint64_t)pos * K + r] = s_D[j * 64 + lane];
+                    // (the enter vertex's row is shared: a read that starts in a later stretch
+                    // has its cell written by that stretch's wave)
+                    const uint32_t dv = s_D[j * 64 + lane];
+                    if (pos > 0 || dv) Dm[(uint64_t)pos * K + r] = dv;
                 }
             }
             if (exit_cell) Am[(uint64_t)exitpos * K + r] = exit_val;
         }
         pos0 += DG_EB;
+    }
+    // the read goes on beyond the stretch: the departure of the last vertex created here needs
+    // the next vertex of the path (the next stretch's wave writes that vertex's arrival side)
+    if (!done && own) {
+        uint32_t q = bbpos, nxt = 0;
+        bool found = false;
+        while (i < hi) {
+            const uint16_t c = buf[i];
+            const uint8_t qb = DG_Q(c), tb = DG_T(c);
+            if (qb == tb) { nxt = bid[q]; found = true; break; }
+            if (qb == DG_GAP) { q++; i++; continue; }
+            if (tb == DG_GAP) { nxt = gbase[q] + Cm[(uint64_t)q * K + r]; found = true; break; }
+            i++;
+        }
+        if (!found) {                                     // nothing but deletions to the end (:106)
+            nxt = bid[exitpos];
+            Am[(uint64_t)exitpos * K + r] = prev + 1u;
+        }
+        const uint32_t pos0 = 0xFFFFFFFFu;                // no row of this departure is staged any more
+        DG_DEPART(nxt);
     }
 #undef DG_DEPART
 #undef DG_COLUMN

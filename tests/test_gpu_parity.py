@@ -103,6 +103,26 @@ def _oracle_graph(batch, t, min_len, trim, merge):
     return g.adjacency(), o2d
 
 
+def _check_graphs(ctx, batch, trim, merge, targets=None):
+    for t in (range(batch.n_targets) if targets is None else targets):
+        got = ctx.debug_graph(t)
+        exp, o2d = _oracle_graph(batch, t, 0, trim, merge)
+        assert len(got) == len(exp) == len(o2d), f"target {t}: vertex count"
+        assert sorted(o2d) == list(range(len(got)))
+        blen = int(batch.tlen[t])
+        for o, (eb, ew, ec, ed, eoe, eie) in enumerate(exp):
+            g = got[o2d[o]]
+            assert g["deleted"] == ed, f"target {t} vertex {o}: deleted flag"
+            assert g["backbone"] == (o < blen + 2)
+            if ed:
+                continue
+            assert (g["base"], g["weight"]) == (eb, ew), f"target {t} vertex {o}: base/weight {g} vs {exp[o]}"
+            if o < blen + 2:
+                assert g["coverage"] == ec, f"target {t} vertex {o}: coverage"
+            assert g["out"] == [(o2d[d], c) for d, c in eoe], f"target {t} vertex {o}: out list"
+            assert g["inn"] == [o2d[s] for s, _ in eie], f"target {t} vertex {o}: in list"
+
+
 @pytest.mark.parametrize("merge", [False, True])
 def test_graph_adjacency_matches_oracle(gpu_ctx_factory, merge):
     """Stage a2 (and b) leave exactly the reference's graph: same vertices, same
@@ -118,23 +138,41 @@ def test_graph_adjacency_matches_oracle(gpu_ctx_factory, merge):
     flags = capi.FLAG_STOP_AFTER_MERGE if merge else capi.FLAG_STOP_AFTER_BUILD
     ctx = gpu_ctx_factory(min_cov=0, min_len=0, trim=2, min_weight=0, flags=flags)
     ctx.consensus(batch)
-    for t in range(batch.n_targets):
-        got = ctx.debug_graph(t)
-        exp, o2d = _oracle_graph(batch, t, 0, 2, merge)
-        assert len(got) == len(exp) == len(o2d), f"target {t}: vertex count"
-        assert sorted(o2d) == list(range(len(got)))
-        blen = int(batch.tlen[t])
-        for o, (eb, ew, ec, ed, eoe, eie) in enumerate(exp):
-            g = got[o2d[o]]
-            assert g["deleted"] == ed, f"target {t} vertex {o}: deleted flag"
-            assert g["backbone"] == (o < blen + 2)
-            if ed:
-                continue
-            assert (g["base"], g["weight"]) == (eb, ew), f"target {t} vertex {o}: base/weight {g} vs {exp[o]}"
-            if o < blen + 2:
-                assert g["coverage"] == ec, f"target {t} vertex {o}: coverage"
-            assert g["out"] == [(o2d[d], c) for d, c in eoe], f"target {t} vertex {o}: out list"
-            assert g["inn"] == [o2d[s] for s, _ in eie], f"target {t} vertex {o}: in list"
+    _check_graphs(ctx, batch, 2, merge)
+
+
+def test_emit_stretches_on_adversarial_pileups(gpu_ctx_factory, monkeypatch):
+    """k_emit threads a read into the graph in stretches of backbone positions, one wave each,
+    entering at recorded columns and looking back / ahead for the neighbouring vertex.  With
+    16-position stretches every kind of column lands on a stretch edge: deletion runs across
+    it, insertion runs in front of it, reads that start or end on it; the built graph and the
+    consensus are the oracle's.  Then the production stretch length on longer targets."""
+    monkeypatch.setenv("DAGCON_EMIT_SHIFT", "4")
+    rng = np.random.default_rng(41)
+    targets = []
+    for i in range(40):
+        tl = int(rng.integers(20, 200))
+        alph = [b"ACGT", b"AC", b"A"][i % 3]
+        alns, bb = random_target(rng, tl, int(rng.integers(1, 10)), alphabet=alph, sub=0.05,
+                                 ins=float(rng.uniform(0.05, 0.3)), dele=float(rng.uniform(0.05, 0.35)),
+                                 dots=(i % 6 == 0), full_span=(i % 2 == 0))
+        targets.append((tl, alns, bb))
+    batch = batch_from_targets(targets)
+    ctx = gpu_ctx_factory(min_cov=0, min_len=0, trim=1, min_weight=0, flags=capi.FLAG_STOP_AFTER_BUILD)
+    ctx.consensus(batch)
+    _check_graphs(ctx, batch, 1, False)
+    _check_batch(gpu_ctx_factory, batch, min_cov=0, min_len=0, trim=0, min_weight=0)
+    _check_batch(gpu_ctx_factory, batch, min_cov=2, min_len=10, trim=3, min_weight=1)
+    monkeypatch.delenv("DAGCON_EMIT_SHIFT")
+    targets = []
+    for i in range(3):
+        tl = int(rng.integers(700, 1700))
+        alns, bb = random_target(rng, tl, 7, alphabet=b"ACGT", sub=0.03, ins=0.12, dele=0.2, full_span=(i != 1))
+        targets.append((tl, alns, bb))
+    batch = batch_from_targets(targets)
+    ctx = gpu_ctx_factory(min_cov=0, min_len=0, trim=3, min_weight=0, flags=capi.FLAG_STOP_AFTER_BUILD)
+    ctx.consensus(batch)
+    _check_graphs(ctx, batch, 3, False)
 
 
 def test_segmented_sweeps_are_exact(gpu_ctx_factory):
@@ -347,7 +385,7 @@ def test_long_gap_runs_take_the_redo_path(gpu_ctx_factory):
         assert (gq, gt, gs) == oracle.trim_aln(qn, tn, s, 7)
 
 
-def test_chunked_normalize_boundaries(gpu_ctx_factory):
+def test_chunked_normalize_boundaries(gpu_ctx_factory, monkeypatch):
     """normalizeGaps runs in chunks of ~1024 input columns that start cold (k_norm_chunk).
     Gaps in flight across chunk starts: an insertion in front of a long dinucleotide repeat
     slides through every chunk start inside it (the chunk in front is run again with the next
@@ -382,6 +420,10 @@ def test_chunked_normalize_boundaries(gpu_ctx_factory):
     tl = 4000
     ta, bb = random_target(rng, tl, 12, alphabet=b"AC", sub=0.04, ins=0.12, dele=0.08, ins_ext=0.4, full_span=True)
     batch = batch_from_targets([(tl, ta, bb)])
+    _check_batch(gpu_ctx_factory, batch, min_cov=0, min_len=0, trim=0, min_weight=0)
+    _check_batch(gpu_ctx_factory, batch, min_cov=4, min_len=100, trim=1030)
+    # k_emit's entry columns next to chunk edges: 16-position stretches put one on every edge
+    monkeypatch.setenv("DAGCON_EMIT_SHIFT", "4")
     _check_batch(gpu_ctx_factory, batch, min_cov=0, min_len=0, trim=0, min_weight=0)
     _check_batch(gpu_ctx_factory, batch, min_cov=4, min_len=100, trim=1030)
 
