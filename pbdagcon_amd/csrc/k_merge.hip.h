@@ -53,6 +53,20 @@ __device__ __forceinline__ void dgg_fail(DgGraph &g, uint32_t bit) {
     if (!g.err) { atomicOr(&g.st->err_flags, bit); g.st->bad_target = g.t; }
     g.err = true;
 }
+// The wave-level code keeps every value that steers control flow provably wave-uniform (the
+// compiler then keeps it in SGPRs and branches without exec masks): g.err of the wave's DgGraph
+// is only ever assigned uniform values.  Single-lane stretches work on a private copy (DG_LANE0).
+__device__ __forceinline__ void dgw_fail(DgGraph &g, uint32_t bit, int lane) {
+    if (lane == 0) { atomicOr(&g.st->err_flags, bit); g.st->bad_target = g.t; }
+    g.err = true;
+}
+#define DG_LANE0(G, BODY)                                          \
+    do {                                                           \
+        bool e_ = false;                                           \
+        if (lane == 0) { DgGraph gs = (G); BODY; e_ = gs.err; }    \
+        DG_WAVE_FENCE();                                           \
+        (G).err = __any((int)e_) != 0;                             \
+    } while (0)
 
 // ---- ordered slot lists (single lane) --------------------------------------
 __device__ inline int dgg_out_find(DgGraph &g, int v, int dst) {
@@ -409,7 +423,7 @@ __device__ __forceinline__ int dg_pick_group(unsigned long long cand, int base, 
 
 __device__ __forceinline__ uint32_t dg_wave_alloc(DgGraph &g, uint32_t words, int lane) {
     uint32_t off = 0;
-    if (lane == 0) off = dgg_alloc(g, words);
+    if (lane == 0) { DgGraph gs = g; off = dgg_alloc(gs, words); }
     off = (uint32_t)DG_RL(off, 0);
     if (off == 0xFFFFFFFFu) g.err = true;                // every lane: keeps control flow uniform
     return off;
@@ -784,12 +798,12 @@ __global__ __launch_bounds__(PF ? 128 : 64) __attribute__((amdgpu_waves_per_eu(8
 #endif
         if (PF && u > prog + 15) { prog = u; if (lane == 0) DG_PROG_SET(u); }
         if (u < c_start || u > c_hi) {                    // cannot happen (see k_cuts): refuse rather than race
-            if (lane == 0) dgg_fail(g, DG_E_INTERNAL);
+            dgw_fail(g, DG_E_INTERNAL, lane);
             break;
         }
         const bool skip_in = seg > 0 && u == c_start;     // the previous segment's worker merges in[u]
         const bool in_only = u == c_end;                  // ... which is this, for the next segment
-        if (in_only && qh != qt) { if (lane == 0) dgg_fail(g, DG_E_INTERNAL); break; }
+        if (in_only && qh != qt) { dgw_fail(g, DG_E_INTERNAL, lane); break; }
 
         // ---------------- the common case in one look: no merge group on either side --------
         {
@@ -874,7 +888,7 @@ __global__ __launch_bounds__(PF ? 128 : 64) __attribute__((amdgpu_waves_per_eu(8
                                 if (pos < N) { g.queue[pos] = nbr; s_ring[pos & (DG_QRING - 1)] = nbr; }
                             }
                             qt += (uint32_t)__popcll(rm);
-                            if (qt > N) { if (lane == 0) dgg_fail(g, DG_E_INTERNAL); g.err = true; }
+                            if (qt > N) dgw_fail(g, DG_E_INTERNAL, lane);
                         }
                         failed = g.err;
 #ifdef DG_STAMPS
@@ -930,12 +944,10 @@ __global__ __launch_bounds__(PF ? 128 : 64) __attribute__((amdgpu_waves_per_eu(8
         if (scalar && !g.err) {
             // finish every open frame, deepest first, on the reference-literal path;
             // groups already merged are gone, so re-evaluating a frame from scratch is exact
-            if (lane == 0) {
-                dgg_merge_in(g, fr_n);
-                for (int f = sp - 2; f >= 0 && !g.err; f--) dgg_merge_in(g, s_stk[2 * f]);
-            }
-            DG_WAVE_FENCE();
-            g.err = __any((int)g.err);
+            DG_LANE0(g, {
+                dgg_merge_in(gs, fr_n);
+                for (int f = sp - 2; f >= 0 && !gs.err; f--) dgg_merge_in(gs, s_stk[2 * f]);
+            });
         }
 
 #ifdef DG_STAMPS
@@ -945,9 +957,7 @@ __global__ __launch_bounds__(PF ? 128 : 64) __attribute__((amdgpu_waves_per_eu(8
         // ---------------- mergeOutNodes(u) + FIFO bookkeeping ----------------
         bool done = false;
         if (scalar) {
-            if (lane == 0 && !g.err) dgg_merge_out(g, u);
-            DG_WAVE_FENCE();
-            g.err = __any((int)g.err);
+            if (!g.err) DG_LANE0(g, { dgg_merge_out(gs, u); });
         }
         int last_out = -1;
         while (!done && !g.err) {
@@ -977,9 +987,7 @@ __global__ __launch_bounds__(PF ? 128 : 64) __attribute__((amdgpu_waves_per_eu(8
                         last_out = b;
                         continue;                         // re-read u's list, look for the next group
                     }
-                    if (lane == 0) dgg_merge_out(g, u);   // a list longer than a wave: literal path
-                    DG_WAVE_FENCE();
-                    g.err = __any((int)g.err);
+                    DG_LANE0(g, { dgg_merge_out(gs, u); });   // a list longer than a wave: literal path
                     scalar = true;
                     continue;
                 }
@@ -994,30 +1002,28 @@ __global__ __launch_bounds__(PF ? 128 : 64) __attribute__((amdgpu_waves_per_eu(8
                 if (pos < N) { g.queue[pos] = d; s_ring[pos & (DG_QRING - 1)] = d; }
             }
             qt += (uint32_t)__popcll(rm);
-            if (qt > N) { if (lane == 0) dgg_fail(g, DG_E_INTERNAL); g.err = true; }
+            if (qt > N) dgw_fail(g, DG_E_INTERNAL, lane);
             done = true;
         }
         if (!done && !g.err) {
             // out list longer than a wave
             uint32_t nqt = qt;
-            if (lane == 0) {
-                if (!scalar) dgg_merge_out(g, u);
-                const uint32_t off = g.nd[u].out_off;
-                const int len = g.nd[u].out_len;
-                for (int i = 0; i < len && !g.err; i++) {
-                    const int v = (int)g.pool[off + 2 * i];
-                    const int pend = g.nd[v].pending - 1;
-                    g.nd[v].pending = pend;
+            DG_LANE0(g, {
+                if (!scalar) dgg_merge_out(gs, u);
+                const uint32_t off = gs.nd[u].out_off;
+                const int len = gs.nd[u].out_len;
+                for (int i = 0; i < len && !gs.err; i++) {
+                    const int v = (int)gs.pool[off + 2 * i];
+                    const int pend = gs.nd[v].pending - 1;
+                    gs.nd[v].pending = pend;
                     if (pend == 0) {
-                        if (nqt >= N) { dgg_fail(g, DG_E_INTERNAL); break; }
+                        if (nqt >= N) { dgg_fail(gs, DG_E_INTERNAL); break; }
                         s_ring[nqt & (DG_QRING - 1)] = v;
-                        g.queue[nqt++] = v;
+                        gs.queue[nqt++] = v;
                     }
                 }
-            }
-            DG_WAVE_FENCE();
+            });
             qt = (uint32_t)DG_RL(nqt, 0);
-            g.err = __any((int)g.err);
         }
         failed = g.err;
 #ifdef DG_STAMPS
