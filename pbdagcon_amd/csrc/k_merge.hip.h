@@ -410,10 +410,12 @@ __device__ __forceinline__ int dg_pick_group(unsigned long long cand, int base, 
                                              unsigned long long *mask) {
     int best = 256;
     unsigned long long bm = 0;
+    // candidates carry their base, every other lane a value no base equals: one compare per round
+    const int key = ((cand >> lane) & 1ull) ? base : -1 - lane;
     while (cand) {
         const int f = __ffsll((long long)cand) - 1;
-        const int b = DG_RL(base, f);
-        const unsigned long long same = __ballot(((cand >> lane) & 1ull) && base == b);
+        const int b = DG_RL(key, f);
+        const unsigned long long same = __ballot(key == b);
         if (b > last && b < best && __popcll(same) >= 2) { best = b; bm = same; }
         cand &= ~same;
     }
@@ -832,8 +834,8 @@ __global__ __launch_bounds__(PF ? 128 : 64) __attribute__((amdgpu_waves_per_eu(8
 #endif
                 uint4 h = make_uint4(0, 0, 0, 0);
                 if (valid) h = dg_lo16(&g.nd[nbr]);
-                const unsigned long long cand =
-                    __ballot(valid && (is_in ? DG_H_OUTLEN(h) == 1 : DG_H_INLEN(h) == 1));
+                // in lanes: out_len == 1 (low half of h.x), out lanes: in_len == 1 (high half)
+                const unsigned long long cand = __ballot(((h.x >> (is_in ? 0u : 16u)) & 0xffffu) == 1u);
 #ifdef DG_STAMPS
                 const unsigned long long tq3 = clock64();
 #endif
