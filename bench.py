@@ -76,7 +76,7 @@ def main():
     ap.add_argument("--targets", type=int, default=1000, help="targets per GPU (configs[1]: 1000)")
     ap.add_argument("--tlen", type=int, default=10000)
     ap.add_argument("--coverage", type=int, default=40)
-    ap.add_argument("--cpu-sample", type=int, default=384, help="targets timed on the CPU oracle")
+    ap.add_argument("--cpu-sample", type=int, default=1000, help="targets timed on the CPU oracle (1000 = ~17 s of CPU work)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--backend", default="nccl",

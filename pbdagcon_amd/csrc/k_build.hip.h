@@ -213,35 +213,34 @@ __device__ inline DgChunkRun dg_norm_run(const uint8_t *q, const uint8_t *t, con
             uint32_t take = len - ip;
             if (take > 16u) take = 16u;
             if (ip < k1 && take > k1 - ip) take = k1 - ip;  // land on the chunk's end exactly
-            unsigned long long q0 = 0, q1 = 0, t0 = 0, t1 = 0;
+#define DG_EXPAND(QB, TB)                                                      \
+            do {                                                               \
+                uint8_t qb_ = (QB), tb_ = (TB);                                \
+                if (qb_ == '.') qb_ = DG_GAP;                                  \
+                if (tb_ == '.') tb_ = DG_GAP;                                  \
+                if (qb_ != tb_ && qb_ != DG_GAP && tb_ != DG_GAP) {            \
+                    DG_W(e) = DG_COL(DG_GAP, tb_); e++;                        \
+                    DG_W(e) = DG_COL(qb_, DG_GAP); e++;                        \
+                } else {                                                       \
+                    DG_W(e) = DG_COL(qb_, tb_); e++;                           \
+                }                                                              \
+            } while (0)
             if (take == 16u && (((uintptr_t)(q + ip)) & 15u) == 0) {
+                // the common case, unrolled: bytes come out of the two 16-byte registers with
+                // constant shifts
                 const uint4 qv = *reinterpret_cast<const uint4 *>(q + ip);
                 const uint4 tv = *reinterpret_cast<const uint4 *>(t + ip);
-                q0 = (unsigned long long)qv.x | ((unsigned long long)qv.y << 32);
-                q1 = (unsigned long long)qv.z | ((unsigned long long)qv.w << 32);
-                t0 = (unsigned long long)tv.x | ((unsigned long long)tv.y << 32);
-                t1 = (unsigned long long)tv.z | ((unsigned long long)tv.w << 32);
+                const uint32_t qw[4] = {qv.x, qv.y, qv.z, qv.w}, tw[4] = {tv.x, tv.y, tv.z, tv.w};
+#pragma unroll
+                for (int k = 0; k < 16; k++)
+                    DG_EXPAND((uint8_t)(qw[k >> 2] >> (8 * (k & 3))), (uint8_t)(tw[k >> 2] >> (8 * (k & 3))));
             } else {
+                // head (up to the next 16-byte boundary) and tail: byte loads
                 const uint32_t to_align = (uint32_t)((16u - (((uintptr_t)(q + ip)) & 15u)) & 15u);
                 if (to_align && take > to_align) take = to_align;
-                for (uint32_t k = 0; k < take; k++) {
-                    const unsigned long long qb = q[ip + k], tbb = t[ip + k];
-                    if (k < 8) { q0 |= qb << (8 * k); t0 |= tbb << (8 * k); }
-                    else { q1 |= qb << (8 * (k - 8)); t1 |= tbb << (8 * (k - 8)); }
-                }
+                for (uint32_t k = 0; k < take; k++) DG_EXPAND(q[ip + k], t[ip + k]);
             }
-            for (uint32_t k = 0; k < take; k++) {
-                uint8_t qb = (uint8_t)((k < 8 ? q0 >> (8 * k) : q1 >> (8 * (k - 8))) & 0xffu);
-                uint8_t tbb = (uint8_t)((k < 8 ? t0 >> (8 * k) : t1 >> (8 * (k - 8))) & 0xffu);
-                if (qb == '.') qb = DG_GAP;
-                if (tbb == '.') tbb = DG_GAP;
-                if (qb != tbb && qb != DG_GAP && tbb != DG_GAP) {
-                    DG_W(e) = DG_COL(DG_GAP, tbb); e++;
-                    DG_W(e) = DG_COL(qb, DG_GAP); e++;
-                } else {
-                    DG_W(e) = DG_COL(qb, tbb); e++;
-                }
-            }
+#undef DG_EXPAND
             ip += take;
             if (ip == k1) e_end = e;
             if (ip == len) in_done = true;
