@@ -59,7 +59,7 @@ struct Ctx {
     DevBuf d_node_base, d_n_nodes, d_pool_base, d_pool_size, d_pool_top, d_t_nins;
     DevBuf d_matA, d_matD, d_matC, d_cov, d_gcount, d_gbase, d_bid;
     DevBuf d_nodes, d_best, d_queue, d_score, d_cns_tmp;
-    DevBuf d_pool, d_stk, d_cuts, d_bp_stat;
+    DevBuf d_pool, d_stk, d_cuts, d_bp_stat, d_bp_len;
     DevBuf d_cns, d_cns_off, d_cns_len, d_seg_first, d_n_seg, d_seg_r0, d_seg_r1, d_st;
 
     uint64_t norm_cap = 0, node_cap = 0, pool_cap = 0, cns_cap = 0, seg_cap = 0;
@@ -141,6 +141,7 @@ int ensure_arenas(Ctx *c) {
     ENSURE(c, c->d_stk, (uint64_t)c->T * c->seg_max * c->stk_words * 4);
     ENSURE(c, c->d_cuts, (uint64_t)c->T * (c->seg_max + 2) * 4);
     ENSURE(c, c->d_bp_stat, (uint64_t)c->T * c->seg_max * 8);
+    ENSURE(c, c->d_bp_len, (uint64_t)c->T * c->seg_max * 4);
     ENSURE(c, c->d_cns, c->cns_cap);
     ENSURE(c, c->d_seg_r0, c->seg_cap * 4);
     ENSURE(c, c->d_seg_r1, c->seg_cap * 4);
@@ -194,7 +195,7 @@ void fill_params(Ctx *c, DgParams &p) {
     // the prefetch wave pays while the chip has idle wave slots; past ~1.5 workers per SIMD the
     // workers hide each other's latency and it only takes issue slots from them
     { const char *e = getenv("DAGCON_PF_AHEAD"); p.pf_ahead = e ? (uint32_t)atoi(e) : ((uint64_t)c->T * c->seg_max >= 1536 ? 0u : 48u); }
-    p.seg_max = c->seg_max; p.seg_min = c->opts.min_segment_len ? c->opts.min_segment_len : 768u; p.cuts = (uint32_t *)c->d_cuts.p; p.bp_stat = (float *)c->d_bp_stat.p;
+    p.seg_max = c->seg_max; p.seg_min = c->opts.min_segment_len ? c->opts.min_segment_len : 768u; p.cuts = (uint32_t *)c->d_cuts.p; p.bp_stat = (float *)c->d_bp_stat.p; p.bp_len = (uint32_t *)c->d_bp_len.p;
     p.cns = (uint8_t *)c->d_cns.p; p.cns_cap = c->cns_cap;
     p.cns_off = (uint64_t *)c->d_cns_off.p; p.cns_len = (uint32_t *)c->d_cns_len.p;
     p.seg_first = (uint64_t *)c->d_seg_first.p; p.n_seg = (uint32_t *)c->d_n_seg.p;
@@ -256,7 +257,9 @@ int launch_all(Ctx *c) {
     if (c->T > 0 && !(c->opts.flags & (DAGCON_FLAG_STOP_AFTER_BUILD | DAGCON_FLAG_STOP_AFTER_MERGE))) {
         hipLaunchKernelGGL(k_bp_prepare, dim3(c->T, 16), dim3(256), 0, s, p);
         hipLaunchKernelGGL(k_bp_sweep, dim3(c->T * c->seg_max), dim3(64), 0, s, p);
-        hipLaunchKernelGGL(k_bp_walk, dim3(c->T), dim3(64), 0, s, p);
+        hipLaunchKernelGGL(k_bp_check, dim3(c->T), dim3(64), 0, s, p);
+        hipLaunchKernelGGL(k_bp_walk, dim3(c->T * c->seg_max), dim3(64), 0, s, p);
+        hipLaunchKernelGGL(k_bp_join, dim3(c->T), dim3(64), 0, s, p);
     }
     HIPCHK(c, hipEventRecord(c->ev[4], s));
     HIPCHK(c, hipGetLastError());
@@ -320,7 +323,7 @@ void dagcon_destroy(dagcon_ctx *ctx) {
                      &c->d_n_ins, &c->d_n_del, &c->d_norm, &c->d_node_base, &c->d_n_nodes,
                      &c->d_pool_base, &c->d_pool_size, &c->d_pool_top, &c->d_t_nins, &c->d_matA, &c->d_matD,
                      &c->d_matC, &c->d_cov, &c->d_gcount, &c->d_gbase, &c->d_bid, &c->d_nodes,
-                     &c->d_best, &c->d_queue, &c->d_score, &c->d_cns_tmp, &c->d_pool, &c->d_stk, &c->d_cuts, &c->d_bp_stat, &c->d_cns,
+                     &c->d_best, &c->d_queue, &c->d_score, &c->d_cns_tmp, &c->d_pool, &c->d_stk, &c->d_cuts, &c->d_bp_stat, &c->d_bp_len, &c->d_cns,
                      &c->d_cns_off, &c->d_cns_len, &c->d_seg_first, &c->d_n_seg, &c->d_seg_r0, &c->d_seg_r1,
                      &c->d_st};
     for (DevBuf *b : all) free_buf(*b);

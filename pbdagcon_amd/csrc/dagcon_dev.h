@@ -148,6 +148,7 @@ struct DgParams {
     uint32_t seg_min;              // shortest backbone stretch worth a worker of its own
     uint32_t *cuts;                // [T][seg_max + 2]: segment count, first vertex of each segment
     float *bp_stat;                // [T][seg_max][2]: largest |score| of the segment, score of its first vertex
+    uint32_t *bp_len;              // [T][seg_max]: vertices of the best path inside the segment (enter / exit excluded)
     // ---- outputs ----
     uint8_t *cns;
     uint64_t cns_cap;

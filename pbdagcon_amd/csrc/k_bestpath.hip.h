@@ -25,9 +25,12 @@
 //                 An edge to a vertex that has no score yet (a turned-around edge) puts
 //                 that vertex on a small stack and it is scored first.  Whatever is not
 //                 in the rings (long lists, far-away successors) comes from HBM.
-//   k_bp_walk     one wave per target: checks that the segmented sweep was exact (else
-//                 sweeps the target in one piece), then the best-edge walk (:443-456) and
-//                 the segmentation (:327-373) on LDS-staged (best, base, weight) triples.
+//   k_bp_check    one wave per target: checks that the segmented sweep was exact, else
+//                 sweeps the target in one piece.
+//   k_bp_walk     one wave per (target, segment): the best-edge walk (:443-456) from one
+//                 cut vertex to the next on LDS-staged (best, base, weight) triples.
+//   k_bp_join     one wave per target: the segmentation (:327-373) over the joined
+//                 pieces, and the output.
 //
 // fp32 throughout; every value is a multiple of 0.5 below 2^23, so the arithmetic is
 // exact (-ffp-contract=off).
@@ -333,7 +336,7 @@ __device__ __forceinline__ void dg_bp_sweep(DgBpShared &S, const DgNode *nd, int
 //     score[x] = (best path x -> next cut) + score[next cut]:
 // the segments are swept concurrently, each relative to its own upper cut, and the
 // first-maximum choices (all that the consensus uses) are the reference's as long as
-// the arithmetic is exact, which k_bp_walk verifies from the figures left here.
+// the arithmetic is exact, which k_bp_check verifies from the figures left here.
 __global__ __launch_bounds__(64) void k_bp_sweep(DgParams p) {
     const uint32_t t = blockIdx.x / p.seg_max, seg = blockIdx.x % p.seg_max;
     if (dg_failed(p) || !p.tactive[t]) return;
@@ -360,145 +363,192 @@ __global__ __launch_bounds__(64) void k_bp_sweep(DgParams p) {
     if (lane == 0) { p.bp_stat[2 * (uint64_t)blockIdx.x] = amax; p.bp_stat[2 * (uint64_t)blockIdx.x + 1] = a; }
 }
 
-// ---- walk and segmentation, one wave per target -----------------------------------
-__global__ __launch_bounds__(64) void k_bp_walk(DgParams p) {
+// ---- exactness check of the segmented sweep, one wave per target -------------------
+__global__ __launch_bounds__(64) void k_bp_check(DgParams p) {
     const uint32_t t = blockIdx.x;
     if (dg_failed(p) || !p.tactive[t]) return;
     const int lane = threadIdx.x;
     const uint64_t nb = p.node_base[t];
-    __shared__ DgBpShared S;
-    __shared__ DgWalkShared W;
-    __shared__ uint32_t s_len, s_nseg;
-    const DgNode *nd = p.nodes + nb;
-    int32_t *best = p.best + nb;
-    const int N = (int)p.n_nodes[t];
-    const int exitv = N - 1;
-    for (int i = lane; i < DG_WR; i += 64) W.wtag[i] = -1;
-    {
-        // Exactness of the segmented sweep: every score is a multiple of 0.5, so fp32 is exact
-        // below 2^23.  A vertex of segment i has the absolute score rel + abs(cut i+1), and a
-        // candidate adds one edge term (|w| <= max(10, reads)); if all of that stays below 2^22
-        // both the reference's absolute arithmetic and the relative one here are exact and pick
-        // the same first maxima.  Otherwise the target is swept again in one piece.
-        const uint32_t *crow = p.cuts + (uint64_t)t * (p.seg_max + 2u);
-        const int nseg = (int)crow[0];
-        bool redo = nseg > 1 && (p.flags & DG_F_RESWEEP);
-        if (nseg > 1) {
-            const float K = (float)(uint32_t)(p.aln_begin[t + 1] - p.aln_begin[t]);
-            const float wmax = K > 10.0f ? K : 10.0f;
-            float acc = 0.0f;
-            for (int i = nseg - 1; i >= 0; i--) {
-                const float m = p.bp_stat[2 * ((uint64_t)t * p.seg_max + i)];
-                const float a = p.bp_stat[2 * ((uint64_t)t * p.seg_max + i) + 1];
-                if (!(m + fabsf(acc) + wmax < 4194304.0f)) redo = true;
-                acc += a;
-            }
-        }
-        if (redo) {
-            float2 *score = p.score + nb;
-            for (int i = lane; i < N; i += 64) score[i] = make_float2(0.0f, 0.0f);
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-            float amax = 0.0f;
-            bool bad = false, stuck = false;
-            dg_bp_sweep(S, nd, best, score, p.pool + p.pool_base[t], N - 1, 0, -1,
-                        p.stk + (uint64_t)t * p.seg_max * p.stk_words, (int)p.stk_words, lane, amax, bad, stuck);
-            if (bad) {
-                if (lane == 0) { dg_fail(p, stuck ? DG_E_INTERNAL : DG_E_STACK); p.st->bad_target = t; }
-                return;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-        }
+    // Every score is a multiple of 0.5, so fp32 is exact below 2^23.  A vertex of segment i has
+    // the absolute score rel + abs(cut i+1), and a candidate adds one edge term
+    // (|w| <= max(10, reads)); if all of that stays below 2^22 both the reference's absolute
+    // arithmetic and the relative one of k_bp_sweep are exact and pick the same first maxima.
+    // Otherwise the target is swept again in one piece.
+    const uint32_t *crow = p.cuts + (uint64_t)t * (p.seg_max + 2u);
+    const int nseg = (int)crow[0];
+    if (nseg <= 1) return;
+    bool redo = (p.flags & DG_F_RESWEEP) != 0;
+    const float K = (float)(uint32_t)(p.aln_begin[t + 1] - p.aln_begin[t]);
+    const float wmax = K > 10.0f ? K : 10.0f;
+    float acc = 0.0f;
+    for (int i = nseg - 1; i >= 0; i--) {
+        const float m = p.bp_stat[2 * ((uint64_t)t * p.seg_max + i)];
+        const float a = p.bp_stat[2 * ((uint64_t)t * p.seg_max + i) + 1];
+        if (!(m + fabsf(acc) + wmax < 4194304.0f)) redo = true;
+        acc += a;
     }
-#ifdef DG_STAMPS
-    const unsigned long long t_begin = clock64(), t_sweep = t_begin;
-    const unsigned long long n_live = 0, n_stack = 0, n_hbm = 0;
-#endif
+    if (!redo) return;
+    __shared__ DgBpShared S;
+    const int N = (int)p.n_nodes[t];
+    float2 *score = p.score + nb;
+    for (int i = lane; i < N; i += 64) score[i] = make_float2(0.0f, 0.0f);
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    float amax = 0.0f;
+    bool bad = false, stuck = false;
+    dg_bp_sweep(S, p.nodes + nb, p.best + nb, score, p.pool + p.pool_base[t], N - 1, 0, -1,
+                p.stk + (uint64_t)t * p.seg_max * p.stk_words, (int)p.stk_words, lane, amax, bad, stuck);
+    if (bad && lane == 0) { dg_fail(p, stuck ? DG_E_INTERNAL : DG_E_STACK); p.st->bad_target = t; }
+}
 
-    // :443-456 walk the best edges from enter; :327-373 segmentation.  Every lane runs the
-    // (uniform) walk so that all of them can stage; lane 0 keeps the results.
-    uint8_t *tmp = p.cns_tmp + nb;
-    int32_t *segs = p.stk + (uint64_t)t * p.seg_max * p.stk_words;      // (range0, range1) pairs
+// ---- the best-edge walk (:443-456), one wave per (target, segment) ----------------
+// The best path passes through every cut vertex, so its stretch from one cut to the next is
+// walked by its own wave.  A segment leaves one byte per path vertex in its own stretch of
+// the scratch (ids of a segment are contiguous): the base, bit 7 = weight >= minWeight.
+__global__ __launch_bounds__(64) void k_bp_walk(DgParams p) {
+    const uint32_t t = blockIdx.x / p.seg_max, seg = blockIdx.x % p.seg_max;
+    if (dg_failed(p) || !p.tactive[t]) return;
+    const uint32_t *crow = p.cuts + (uint64_t)t * (p.seg_max + 2u);
+    const uint32_t nseg = crow[0];
+    if (seg >= nseg) return;
+    const int lane = threadIdx.x;
+    const uint64_t nb = p.node_base[t];
+    __shared__ DgWalkShared W;
+    const DgNode *nd = p.nodes + nb;
+    const int32_t *best = p.best + nb;
+    const int N = (int)p.n_nodes[t];
+    for (int i = lane; i < DG_WR; i += 64) W.wtag[i] = -1;
+    const int c0 = (int)crow[1 + seg];
+    const int c1 = seg + 1 < nseg ? (int)crow[2 + seg] : -1;
+    const uint8_t eb = nd[0].base, xb = nd[N - 1].base;
+    const int minw = p.min_weight;
+    uint8_t *tmp = p.cns_tmp + nb + c0;
+    int v = c0, cs = c0 >> 6, idx = 0;
+    uint32_t steps = 0;
+    bool bad = false;
+    for (;;) {
+        if (v == c1) break;                                  // the next segment starts here
+        while (64 * cs < N && 64 * cs < v + 192) {           // (best, base, weight) of 64 ids ahead
+            const int id = 64 * cs + lane;
+            if (id < N) {
+                const uint4 h = *reinterpret_cast<const uint4 *>(&nd[id]);
+                const int b = best[id];
+                const int xw = id & (DG_WR - 1);
+                W.wtag[xw] = id; W.wbest[xw] = b; W.wbase[xw] = (int)(h.y & 0xffu); W.wweight[xw] = (int)h.z;
+            }
+            cs++;
+        }
+        const int xw = v & (DG_WR - 1);
+        int nxt, w;
+        uint8_t base;
+        const int wt = W.wtag[xw], wb = W.wbest[xw], wa = W.wbase[xw], ww = W.wweight[xw];
+        if (__builtin_amdgcn_readfirstlane(wt) == v) {
+            nxt = __builtin_amdgcn_readfirstlane(wb); base = (uint8_t)__builtin_amdgcn_readfirstlane(wa);
+            w = __builtin_amdgcn_readfirstlane(ww);
+        } else {
+            const uint4 h = *reinterpret_cast<const uint4 *>(&nd[v]);
+            nxt = __builtin_amdgcn_readfirstlane(best[v]);
+            base = (uint8_t)__builtin_amdgcn_readfirstlane((int)(h.y & 0xffu));
+            w = __builtin_amdgcn_readfirstlane((int)h.z);
+        }
+        if (!(base == eb || base == xb)) {
+            if (lane == 0) W.wbuf[idx & 63] = (unsigned char)(base | (w >= minw ? 0x80u : 0u));
+            if ((idx & 63) == 63) tmp[(idx & ~63) + lane] = W.wbuf[lane];
+            idx++;
+        }
+        if (nxt < 0) break;
+        v = nxt;
+        if (++steps > (uint32_t)N) { bad = true; break; }
+    }
+    if (lane < (idx & 63)) tmp[(idx & ~63) + lane] = W.wbuf[lane];     // the last, partial row
+    if (lane == 0) {
+        if (bad) { dg_fail(p, DG_E_INTERNAL); p.st->bad_target = t; }
+        p.bp_len[blockIdx.x] = (uint32_t)idx;
+    }
+}
+
+// ---- consensus segmentation (:327-373) and output, one wave per target ------------
+__global__ __launch_bounds__(64) void k_bp_join(DgParams p) {
+    const uint32_t t = blockIdx.x;
+    if (dg_failed(p) || !p.tactive[t]) return;
+    const int lane = threadIdx.x;
+    const uint64_t nb = p.node_base[t];
+    const uint32_t *crow = p.cuts + (uint64_t)t * (p.seg_max + 2u);
+    const uint32_t nseg = crow[0];
+    __shared__ uint32_t s_off[65], s_c0[64];
     {
-        const uint8_t eb = nd[0].base, xb = nd[exitv].base;
-        const int minw = p.min_weight;
-        const uint32_t minlen = p.min_len;
-        const uint32_t seg_cap = p.stk_words / 2;
-        int v = 0, cs = 0;
-        int offs = 0, idx = 0;
-        bool met = false;
-        uint32_t nseg = 0, steps = 0;
-        bool ovf = false;
-        for (;;) {
-            while (64 * cs < N && 64 * cs < v + 192) {       // (best, base, weight) of 64 ids ahead
-                const int id = 64 * cs + lane;
-                if (id < N) {
-                    const uint4 h = *reinterpret_cast<const uint4 *>(&nd[id]);
-                    const int b = best[id];
-                    const int xw = id & (DG_WR - 1);
-                    W.wtag[xw] = id; W.wbest[xw] = b; W.wbase[xw] = (int)(h.y & 0xffu); W.wweight[xw] = (int)h.z;
-                }
-                cs++;
-            }
-            const int xw = v & (DG_WR - 1);
-            int nxt, w;
-            uint8_t base;
-            const int wt = W.wtag[xw], wb = W.wbest[xw], wa = W.wbase[xw], ww = W.wweight[xw];
-            if (__builtin_amdgcn_readfirstlane(wt) == v) {
-                nxt = __builtin_amdgcn_readfirstlane(wb); base = (uint8_t)__builtin_amdgcn_readfirstlane(wa);
-                w = __builtin_amdgcn_readfirstlane(ww);
-            } else {
-                const uint4 h = *reinterpret_cast<const uint4 *>(&nd[v]);
-                nxt = __builtin_amdgcn_readfirstlane(best[v]);
-                base = (uint8_t)__builtin_amdgcn_readfirstlane((int)(h.y & 0xffu));
-                w = __builtin_amdgcn_readfirstlane((int)h.z);
-            }
-            if (!(base == eb || base == xb)) {
-                if (lane == 0) W.wbuf[idx & 63] = base;
-                if ((idx & 63) == 63) tmp[(idx & ~63) + lane] = W.wbuf[lane];
-                if (!met && w >= minw) { offs = idx; met = true; }
-                else if (met && w < minw) {
+        // where each segment's piece of the path goes (seg_max <= 64: one lane per segment)
+        const uint32_t len = (uint32_t)lane < nseg ? p.bp_len[(uint64_t)t * p.seg_max + lane] : 0u;
+        uint32_t incl = len;
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t up = __shfl_up(incl, o); if (lane >= o) incl += up; }
+        s_off[lane] = incl - len;
+        if (lane == 63) s_off[64] = incl;
+        s_c0[lane] = (uint32_t)lane < nseg ? crow[1 + lane] : 0u;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    const uint32_t total = s_off[64];
+    const uint8_t *tmp = p.cns_tmp + nb;
+    int32_t *segs = p.stk + (uint64_t)t * p.seg_max * p.stk_words;      // (range0, range1) pairs
+    const uint32_t seg_cap = p.stk_words / 2;
+    const uint32_t minlen = p.min_len;
+    // every maximal run of path vertices with weight >= minWeight that is long enough
+    bool met = false, ovf = false;
+    uint32_t offs = 0, nout = 0, keep = 0;
+    for (uint32_t s = 0; s < nseg; s++) {
+        const uint32_t len = s_off[s + 1 < 64 ? s + 1 : 64] - s_off[s], g0s = s_off[s];
+        const uint8_t *src = tmp + s_c0[s];
+        for (uint32_t j0 = 0; j0 < len; j0 += 64) {
+            const uint32_t n = len - j0 < 64 ? len - j0 : 64;
+            const bool valid = (uint32_t)lane < n;
+            const uint32_t b = valid ? src[j0 + lane] : 0u;
+            const unsigned long long vm = n == 64 ? ~0ull : ((1ull << n) - 1ull);
+            const unsigned long long m = __ballot(valid && (b >> 7));
+            uint32_t pos = 0;
+            while (pos < n) {
+                const unsigned long long look = (met ? (~m & vm) : m) >> pos;
+                if (!look) break;
+                const uint32_t f = pos + (uint32_t)__ffsll((long long)look) - 1u;
+                const uint32_t g = g0s + j0 + f;
+                if (!met) { offs = g; met = true; }
+                else {
                     met = false;
-                    if ((uint32_t)(idx - offs) >= minlen) {
-                        if (nseg < seg_cap) { if (lane == 0) { segs[2 * nseg] = offs; segs[2 * nseg + 1] = idx; } nseg++; }
+                    if (g - offs >= minlen) {
+                        if (nout < seg_cap) { if (lane == 0) { segs[2 * nout] = (int)offs; segs[2 * nout + 1] = (int)g; } nout++; keep = g; }
                         else ovf = true;
                     }
                 }
-                idx++;
+                pos = f + 1;
             }
-            if (nxt < 0) break;
-            v = nxt;
-            if (++steps > (uint32_t)N) { ovf = true; break; }
         }
-        if (met && (uint32_t)(idx - offs) >= minlen) {
-            if (nseg < seg_cap) { if (lane == 0) { segs[2 * nseg] = offs; segs[2 * nseg + 1] = idx; } nseg++; }
-            else ovf = true;
-        }
-        // only the bases some segment covers are shipped
-        if (lane < (idx & 63)) tmp[(idx & ~63) + lane] = W.wbuf[lane];     // the last, partial row
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-        if (lane == 0) {
-            if (ovf) dg_fail(p, DG_E_STACK);
-            uint32_t keep = nseg ? (uint32_t)segs[2 * (nseg - 1) + 1] : 0u;
-            const unsigned long long co = atomicAdd(&p.st->cns_top, (unsigned long long)keep);
-            const unsigned long long so = atomicAdd(&p.st->seg_top, (unsigned long long)nseg);
-            if (co + keep > p.cns_cap || so + nseg > p.seg_cap) { dg_fail(p, DG_E_OUT_OVF); keep = 0; nseg = 0; }
-            p.cns_off[t] = co; p.cns_len[t] = keep;
-            p.seg_first[t] = so; p.n_seg[t] = nseg;
-            s_len = keep; s_nseg = nseg;
-        }
+    }
+    if (met && total - offs >= minlen) {
+        if (nout < seg_cap) { if (lane == 0) { segs[2 * nout] = (int)offs; segs[2 * nout + 1] = (int)total; } nout++; keep = total; }
+        else ovf = true;
+    }
+    // only the bases some segment covers are shipped
+    __shared__ unsigned long long s_co, s_so;
+    if (lane == 0) {
+        if (ovf) dg_fail(p, DG_E_STACK);
+        unsigned long long co = atomicAdd(&p.st->cns_top, (unsigned long long)keep);
+        unsigned long long so = atomicAdd(&p.st->seg_top, (unsigned long long)nout);
+        if (co + keep > p.cns_cap || so + nout > p.seg_cap) { dg_fail(p, DG_E_OUT_OVF); s_co = ~0ull; }
+        else s_co = co;
+        s_so = so;
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-#ifdef DG_STAMPS
-    if (t == 0 && lane == 0) {
-        unsigned long long *d = p.st->dbg;
-        d[0] = n_live; d[1] = n_stack; d[2] = n_hbm; d[5] = t_sweep - t_begin; d[6] = clock64() - t_sweep;
+    const unsigned long long co = s_co, so = s_so;
+    if (co == ~0ull) { keep = 0; nout = 0; }
+    if (lane == 0) {
+        p.cns_off[t] = co == ~0ull ? 0ull : co; p.cns_len[t] = keep;
+        p.seg_first[t] = so; p.n_seg[t] = nout;
     }
-#endif
-    const uint32_t keep = s_len, nseg = s_nseg;
-    uint8_t *out = p.cns + p.cns_off[t];
-    for (uint32_t i = lane; i < keep; i += 64) out[i] = tmp[i];
-    const uint64_t so = p.seg_first[t];
-    for (uint32_t i = lane; i < nseg; i += 64) {
+    if (co == ~0ull) return;
+    uint8_t *out = p.cns + co;
+    for (uint32_t s = 0; s < nseg; s++) {
+        const uint32_t g0s = s_off[s], len = s_off[s + 1 < 64 ? s + 1 : 64] - s_off[s];
+        const uint8_t *src = tmp + s_c0[s];
+        for (uint32_t j = lane; j < len && g0s + j < keep; j += 64) out[g0s + j] = (uint8_t)(src[j] & 0x7fu);
+    }
+    for (uint32_t i = lane; i < nout; i += 64) {
         p.seg_r0[so + i] = segs[2 * i];
         p.seg_r1[so + i] = segs[2 * i + 1];
     }
