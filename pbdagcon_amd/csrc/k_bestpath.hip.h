@@ -69,10 +69,12 @@ __global__ __launch_bounds__(256) void k_bp_prepare(DgParams p) {
 // LDS per sweep wave is what bounds the waves in flight (8 segments x 1000 targets want
 // ~8 KB each): only the chunk being swept needs its edges staged, and successors are
 // almost always within a few hundred ids
-#define DG_BR 64             // staged vertices (id & 63): the chunk being swept
+#ifndef DG_SR
 #define DG_SR 256            // finished scores (id & 255)
-#define DG_WR 256            // the walk's staging ring
 #define DG_BOUT 6            // out edges kept in a staged slot
+#endif
+#define DG_BR 64             // staged vertices (id & 63): the chunk being swept
+#define DG_WR 256            // the walk's staging ring
 #define DG_BSTK 64           // vertices waiting for a successor's score
 #define DG_BL_HBM  0x40000000  // lens: the edges did not fit the slot
 #define DG_BL_DONE 0x20000000  // lens: scored already

@@ -1043,6 +1043,13 @@ __global__ __launch_bounds__(256) void k_lists(DgParams p) {
                 val = (cell != 0u && idf != DG_CELL_DEL) ? (int32_t)idf : 0;
             }
             unsigned long long rem = __ballot(val != 0);
+            if (!in_lds) {
+                // the constructor's neighbour (entry 0) takes most of the row: no peeling round for it
+                const int32_t chain = __builtin_amdgcn_readlane(lv, 0) + 1;
+                const unsigned long long cm = __ballot(val == chain);
+                if (lane == 0) lc += __popcll(cm);
+                rem &= ~cm;
+            }
             while (rem) {
                 const int first = __ffsll((long long)rem) - 1;
                 const int32_t x = __builtin_amdgcn_readlane(val, first);
