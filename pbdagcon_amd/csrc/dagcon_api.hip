@@ -235,7 +235,7 @@ int launch_all(Ctx *c) {
     }
     hipLaunchKernelGGL(k_carve, dim3(1), dim3(1024), 0, s, p);
     if (c->T > 0) {
-        const uint32_t rows4 = (c->max_tlen + 2 + 3) / 4;
+        const uint32_t rows4 = (c->max_tlen + 2 + 4 * DG_LPW - 1) / (4 * DG_LPW);   // 4 waves x DG_LPW positions per block
         hipLaunchKernelGGL(k_groups, dim3(c->T, rows4), dim3(256), 0, s, p);
         hipLaunchKernelGGL(k_gscan, dim3(c->T), dim3(1024), 0, s, p);
         hipLaunchKernelGGL(k_init_nodes, dim3(c->T, (c->max_tlen + 2 + 255) / 256), dim3(256), 0, s, p);

@@ -18,6 +18,9 @@
 #include "dagcon_dev.h"
 
 #define DG_WAVE 64
+#ifndef DG_LPW
+#define DG_LPW 8u             // positions per wave of k_lists / k_groups
+#endif
 
 __device__ __forceinline__ bool dg_failed(const DgParams &p) {
     return __hip_atomic_load(&p.st->err_flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
@@ -643,10 +646,13 @@ __global__ __launch_bounds__(256) void k_groups(DgParams p) {
     if (dg_failed(p) || !p.tactive[t]) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t blen = p.tlen[t];
-    const uint32_t pos = blockIdx.y * 4 + wave;
-    if (pos >= blen + 2) return;
     const uint32_t K = (uint32_t)(p.aln_begin[t + 1] - p.aln_begin[t]);
-    uint32_t *row = p.matC + p.mat_base[t] + (uint64_t)pos * K;
+    uint32_t *row0 = p.matC + p.mat_base[t];
+    uint32_t *gcount = p.gcount + p.bbv_base[t];
+    for (uint32_t pi = 0; pi < DG_LPW; pi++) {
+    const uint32_t pos = (blockIdx.y * 4 + wave) * DG_LPW + pi;
+    if (pos >= blen + 2) return;
+    uint32_t *row = row0 + (uint64_t)pos * K;
     uint32_t carry = 0;
     for (uint32_t r0 = 0; r0 < K; r0 += DG_WAVE) {
         const uint32_t r = r0 + lane;
@@ -659,7 +665,8 @@ __global__ __launch_bounds__(256) void k_groups(DgParams p) {
         if (r < K) row[r] = carry + incl - v;
         carry += __shfl(incl, DG_WAVE - 1);
     }
-    if (lane == 0) p.gcount[p.bbv_base[t] + pos] = carry;
+    if (lane == 0) gcount[pos] = carry;
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -746,8 +753,10 @@ __global__ __launch_bounds__(256) void k_init_nodes(DgParams p) {
 #ifndef DG_ERPW
 #define DG_ERPW 64          // reads per wave (16 or 32 were tried: no faster)
 #endif
+#ifndef DG_ECOLS
 #define DG_ECOLS 48u          // columns staged in LDS per lane and batch (6 x 16 bytes)
 #define DG_ECOLS_STRIDE 50u   // 25 dwords per lane row: odd, lanes spread over banks
+#endif
 __global__ __launch_bounds__(64) void k_emit(DgParams p) {
     __shared__ uint32_t s_D[DG_EB * 64];
     __shared__ uint16_t s_col[64 * DG_ECOLS_STRIDE];
@@ -998,20 +1007,24 @@ __global__ __launch_bounds__(256) void k_lists(DgParams p) {
     if (dg_failed(p) || !p.tactive[t]) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t blen = p.tlen[t];
-    const uint32_t pos = blockIdx.y * 4 + wave;
-    if (pos >= blen + 2) return;
     const uint32_t K = (uint32_t)(p.aln_begin[t + 1] - p.aln_begin[t]);
     const uint32_t stride = p.max_k + 2;
     volatile int32_t *vals = s_tmp + (size_t)wave * 2 * stride;
     volatile int32_t *cnts = vals + stride;
     const uint64_t nb = p.node_base[t];
     const uint64_t bv = p.bbv_base[t];
-    const uint32_t v = p.bid[bv + pos];
     uint32_t *pool = p.pool + p.pool_base[t];
-    const uint32_t *Am = p.matA + p.mat_base[t] + (uint64_t)pos * K;
-    const uint32_t *Dm = p.matD + p.mat_base[t] + (uint64_t)pos * K;
+    const uint32_t *Am0 = p.matA + p.mat_base[t], *Dm0 = p.matD + p.mat_base[t];
     const uint32_t capb = dg_capb(K);
-    const uint32_t fixed = 3u * p.t_nins[t] + pos * 3u * capb;
+    const uint32_t fixed0 = 3u * p.t_nins[t];
+    // a wave takes DG_LPW consecutive positions: the set-up above is paid once for them
+    for (uint32_t pi = 0; pi < DG_LPW; pi++) {
+    const uint32_t pos = (blockIdx.y * 4 + wave) * DG_LPW + pi;
+    if (pos >= blen + 2) return;
+    const uint32_t v = p.bid[bv + pos];
+    const uint32_t *Am = Am0 + (uint64_t)pos * K;
+    const uint32_t *Dm = Dm0 + (uint64_t)pos * K;
+    const uint32_t fixed = fixed0 + pos * 3u * capb;
     uint32_t out_off = fixed, in_off = fixed + 2u * capb;
     uint32_t out_cap = capb, in_cap = capb;
     uint32_t out_len = 0, in_len = 0;
@@ -1113,5 +1126,6 @@ __global__ __launch_bounds__(256) void k_lists(DgParams p) {
             p.cov[bv + pos] = (int32_t)n_cov;                   // :76,:87
         }
         p.nodes[nb + v] = nd;
+    }
     }
 }
