@@ -210,7 +210,8 @@ void launch_normalize(Ctx *c, const DgParams &p) {
     if (c->A == 0) return;
     (void)hipMemsetAsync(c->d_ckpt.p, 0xFF, c->n_ckpt * 4, s);
     hipLaunchKernelGGL(k_count, dim3(c->A), dim3(256), 0, s, p);
-    hipLaunchKernelGGL(k_norm_chunk, dim3((c->n_chunks + 63) / 64), dim3(64), 0, s, p);
+    hipLaunchKernelGGL((k_norm_chunk<DG_NW, 64, false>), dim3((c->n_chunks + 63) / 64), dim3(64), 0, s, p);
+    hipLaunchKernelGGL((k_norm_chunk<DG_NW_BIG, 32, true>), dim3((c->n_chunks + 31) / 32), dim3(32), 0, s, p);
     hipLaunchKernelGGL(k_norm_scan, dim3((c->A + 63) / 64), dim3(64), 0, s, p);
     hipLaunchKernelGGL(k_norm_finish, dim3((c->n_chunks + 63) / 64), dim3(64), 0, s, p);
     hipLaunchKernelGGL(k_normalize_slow, dim3((c->A + 63) / 64), dim3(64), 0, s, p);

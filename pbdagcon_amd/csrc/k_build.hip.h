@@ -79,10 +79,9 @@ __global__ __launch_bounds__(256) void k_count(DgParams p) {
 #define DG_COL(qb, tb) ((uint16_t)((uint16_t)(qb) | ((uint16_t)(tb) << 8)))
 #define DG_Q(c) ((uint8_t)((c) & 0xff))
 #define DG_T(c) ((uint8_t)((c) >> 8))
-#ifndef DG_NW
-#define DG_NW 128u            // LDS window: columns per lane (power of two)
-#define DG_NW_STRIDE 130u     // uint16 per lane row: 65 dwords, odd, so lanes spread over banks
-#endif
+#define DG_NW 64u             // LDS window of the first pass: columns per lane (power of two); the lane
+                              // row is NW + 2 uint16 = an odd number of dwords, so lanes spread over banks
+#define DG_NW_BIG 512u        // window of the second pass, for the chunks whose look-ahead outgrew the first
 #define DG_REDO 0xFFFFFFFFu   // n_hi marker: redo on the slow path
 
 // trimAln, column counts, conformity, insertion runs: what follows normalizeGaps for
@@ -197,9 +196,10 @@ struct DgChunkRun { uint32_t w, tb; bool dirty, overflow; };
 
 // normalizeGaps (Alignment.cpp:142-214) on the input columns [k0, k1) of an alignment, started
 // cold; the look-ahead may read (and, reported as `dirty`, write) beyond k1.
+template <uint32_t NW>
 __device__ inline DgChunkRun dg_norm_run(const uint8_t *q, const uint8_t *t, const uint32_t len, const uint32_t k0,
                                          const uint32_t k1, uint16_t *win, uint16_t *out) {
-#define DG_W(x) win[(x) & (DG_NW - 1u)]
+#define DG_W(x) win[(x) & (NW - 1u)]
     DgChunkRun r;
     r.w = 0; r.tb = 0; r.dirty = false; r.overflow = false;
     if (k0 >= k1) return r;
@@ -212,7 +212,7 @@ __device__ inline DgChunkRun dg_norm_run(const uint8_t *q, const uint8_t *t, con
     for (;;) {
         // ---- refill: Alignment.cpp:142-159 on the next (up to) 16 input columns ----
         if (!in_done) {
-            if ((e - i) + 32u > DG_NW) { r.overflow = true; break; }
+            if ((e - i) + 32u > NW) { r.overflow = true; break; }
             uint32_t take = len - ip;
             if (take > 16u) take = 16u;
             if (ip < k1 && take > k1 - ip) take = k1 - ip;  // land on the chunk's end exactly
@@ -300,13 +300,19 @@ __device__ inline DgChunkRun dg_norm_run(const uint8_t *q, const uint8_t *t, con
     return r;
 }
 
-__global__ __launch_bounds__(64) void k_norm_chunk(DgParams p) {
-    __shared__ uint16_t s_win[64 * DG_NW_STRIDE];
+// NW = 64 keeps the LDS footprint of the first pass at 8 KB per wave (the kernel is bound by waves in
+// flight); a chunk whose look-ahead outgrows that window (a gap run of ~30 columns) is done again
+// by the second pass (RETRY: LANES = 32 lanes per block, a 512-column window each), and only what
+// outgrows that one too sends its alignment to k_normalize_slow.
+template <uint32_t NW, uint32_t LANES, bool RETRY>
+__global__ __launch_bounds__(LANES) void k_norm_chunk(DgParams p) {
+    __shared__ uint16_t s_win[LANES * (NW + 2u)];
     // neighbouring chunks are ~1 KB of input (4 KB of scratch) apart: lanes of a wave take chunks
     // a whole grid apart instead, or their lines fight for the same few L1 sets and L2 channels
     const uint32_t g = threadIdx.x * gridDim.x + blockIdx.x;
     if (g >= p.n_chunks) return;
     if (dg_failed(p)) return;
+    if (RETRY && p.ch_flag[g] != 2u) return;
     const uint32_t a = p.ch_aln[g];
     const uint32_t c = g - p.ch_base[a], nwin = p.ch_base[a + 1] - p.ch_base[a];
     const uint64_t off = p.aln_off[a];
@@ -322,7 +328,7 @@ __global__ __launch_bounds__(64) void k_norm_chunk(DgParams p) {
     } else {
         k0 = dg_chunk_start(q, t, len, c);
         if (k0 != DG_CH_NONE) {
-            uint16_t *win = s_win + threadIdx.x * DG_NW_STRIDE;
+            uint16_t *win = s_win + threadIdx.x * (NW + 2u);
             src = (2ull * (off + k0) + 8ull * g + 7ull) & ~7ull;     // 16-byte aligned, regions stay disjoint
             for (;;) {
                 uint32_t k1 = len;
@@ -330,8 +336,8 @@ __global__ __launch_bounds__(64) void k_norm_chunk(DgParams p) {
                     const uint32_t s = dg_chunk_start(q, t, len, cn);
                     if (s != DG_CH_NONE) { k1 = s; break; }
                 }
-                r = dg_norm_run(q, t, len, k0, k1, win, p.norm_tmp + src);
-                if (r.overflow) { flag = 1; break; }
+                r = dg_norm_run<NW>(q, t, len, k0, k1, win, p.norm_tmp + src);
+                if (r.overflow) { flag = RETRY ? 1u : 2u; break; }
                 if (!r.dirty) break;
                 // a gap in flight got past the end: once more with the next chunk taken in,
                 // into a stretch of the re-run region
@@ -361,7 +367,7 @@ __global__ __launch_bounds__(64) void k_norm_scan(DgParams p) {
     uint32_t m = 0, tbt = 0;
     for (uint32_t g = g0; g < g1;) {
         if (p.ch_k0[g] == DG_CH_NONE) { p.ch_out[g] = DG_CH_NONE; g++; continue; }
-        redo |= p.ch_flag[g] != 0;
+        redo |= p.ch_flag[g] != 0;                       // (1: too long even for the second pass, or no scratch left)
         p.ch_out[g] = m; p.ch_adv[g] = tbt;
         m += p.ch_w[g]; tbt += p.ch_tb[g];
         uint32_t nx = g0 + p.ch_next[g];

@@ -352,8 +352,9 @@ def test_deep_coverage_more_than_one_wave(gpu_ctx_factory):
 
 
 def test_long_gap_runs_take_the_redo_path(gpu_ctx_factory):
-    """Gap runs longer than k_normalize's LDS window (an insertion or deletion of hundreds of
-    columns, homopolymers a gap slides through) are redone by k_normalize_slow; same answer."""
+    """Gap runs longer than k_norm_chunk's LDS windows (an insertion or deletion of hundreds of
+    columns, homopolymers a gap slides through) take its second pass (512-column window) or
+    k_normalize_slow; same answer."""
     rng = np.random.default_rng(21)
     tl = 900
     alns, bb = random_target(rng, tl, 8, alphabet=b"ACGT", full_span=True, sub=0.02, ins=0.08, dele=0.04)
@@ -364,9 +365,10 @@ def test_long_gap_runs_take_the_redo_path(gpu_ctx_factory):
     for k in range(6):
         q, t = bytearray(), bytearray()
         for i in range(tl):
-            if k % 3 == 0 and i == 200:            # 300-column insertion
-                ins = bytes(b"ACGT"[j] for j in rng.integers(0, 4, 300))
-                q += ins; t += b"-" * 300
+            if k % 3 == 0 and i == 200:            # 300-column insertion (second pass of k_norm_chunk);
+                n_ins = 300 if k == 0 else 700     # 700 columns: beyond its window too, k_normalize_slow
+                ins = bytes(b"ACGT"[j] for j in rng.integers(0, 4, n_ins))
+                q += ins; t += b"-" * n_ins
             if k % 3 == 1 and 600 <= i < 850:      # 250-column deletion
                 q.append(0x2D); t.append(bb[i]); continue
             if k % 3 == 2 and i == 299:            # an 'A' inserted in front of the homopolymer:
