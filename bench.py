@@ -113,15 +113,22 @@ def main():
     ctx = capi.Context(device=local_rank, **opts)
     ctx.upload(batch)                       # inputs resident in HBM from here on
 
-    def step():
-        ctx.run()
-        res = ctx.fetch()
-        if dist is not None:
-            return res, gather_fasta(fasta_bytes(batch, res), dist, torch, local_rank)
-        return res, None
+    def gather(res):
+        return gather_fasta(fasta_bytes(batch, res), dist, torch, local_rank) if dist is not None else None
 
+    def step(prev):
+        """One pass of the hot path over the batch, results on the host.  The FASTA gather of the
+        previous step's results (host formatting + RCCL) runs while this step's kernels are on
+        the device; the last step's gather is done before the closing fence."""
+        ctx.run()
+        g = gather(prev) if prev is not None else None
+        return ctx.fetch(), g
+
+    res = None
     for _ in range(args.warmup):
-        res, _ = step()
+        res, _ = step(res)
+    if res is not None:
+        gather(res)
 
     def fence():
         if dist is not None:
@@ -131,11 +138,13 @@ def main():
     merge_ms, total_ms = [], []
     fence()
     t0 = time.perf_counter()
+    res = None
     for _ in range(args.steps):
-        res, gathered = step()
+        res, _ = step(res)
         tm = ctx.timings()
         merge_ms.append(tm["ms_merge"])
         total_ms.append(tm["ms_total"])
+    gathered = gather(res)
     fence()
     dt = time.perf_counter() - t0
     if dist is not None:
