@@ -58,7 +58,7 @@ struct Ctx {
         d_n_lb, d_norm_tmp, d_ckpt, d_ck_base;
     DevBuf d_node_base, d_n_nodes, d_pool_base, d_pool_size, d_pool_top, d_t_nins;
     DevBuf d_matA, d_matD, d_matC, d_cov, d_gcount, d_gbase, d_bid;
-    DevBuf d_nodes, d_best, d_queue, d_score, d_cns_tmp;
+    DevBuf d_nodes, d_best, d_queue, d_score, d_cns_tmp, d_bp_tt;
     DevBuf d_pool, d_stk, d_cuts, d_bp_stat, d_bp_len;
     DevBuf d_cns, d_cns_off, d_cns_len, d_seg_first, d_n_seg, d_seg_r0, d_seg_r1, d_st;
 
@@ -136,6 +136,7 @@ int ensure_arenas(Ctx *c) {
     ENSURE(c, c->d_best, c->node_cap * 4);
     ENSURE(c, c->d_queue, c->node_cap * 4);
     ENSURE(c, c->d_score, c->node_cap * 8);
+    ENSURE(c, c->d_bp_tt, c->node_cap * 4);
     ENSURE(c, c->d_cns_tmp, c->node_cap);
     ENSURE(c, c->d_pool, c->pool_cap * 4);
     ENSURE(c, c->d_stk, (uint64_t)c->T * c->seg_max * c->stk_words * 4);
@@ -188,7 +189,7 @@ void fill_params(Ctx *c, DgParams &p) {
     p.cov = (int32_t *)c->d_cov.p; p.gcount = (uint32_t *)c->d_gcount.p;
     p.gbase = (uint32_t *)c->d_gbase.p; p.bid = (uint32_t *)c->d_bid.p;
     p.nodes = (DgNode *)c->d_nodes.p; p.best = (int32_t *)c->d_best.p;
-    p.queue = (int32_t *)c->d_queue.p; p.score = (float2 *)c->d_score.p;
+    p.queue = (int32_t *)c->d_queue.p; p.score = (float2 *)c->d_score.p; p.bp_tt = (float *)c->d_bp_tt.p;
     p.cns_tmp = (uint8_t *)c->d_cns_tmp.p; p.node_cap = c->node_cap;
     p.pool = (uint32_t *)c->d_pool.p; p.pool_cap = c->pool_cap;
     p.stk = (int32_t *)c->d_stk.p; p.stk_words = c->stk_words; p.growth_pct = c->growth_pct;
@@ -256,6 +257,7 @@ int launch_all(Ctx *c) {
     }
     HIPCHK(c, hipEventRecord(c->ev[3], s));
     if (c->T > 0 && !(c->opts.flags & (DAGCON_FLAG_STOP_AFTER_BUILD | DAGCON_FLAG_STOP_AFTER_MERGE))) {
+        hipLaunchKernelGGL(k_bp_terms, dim3(c->T, 16), dim3(256), 0, s, p);
         hipLaunchKernelGGL(k_bp_prepare, dim3(c->T, 16), dim3(256), 0, s, p);
         hipLaunchKernelGGL(k_bp_sweep, dim3(c->T * c->seg_max), dim3(64), 0, s, p);
         hipLaunchKernelGGL(k_bp_check, dim3(c->T), dim3(64), 0, s, p);
@@ -324,7 +326,7 @@ void dagcon_destroy(dagcon_ctx *ctx) {
                      &c->d_n_ins, &c->d_n_del, &c->d_norm, &c->d_node_base, &c->d_n_nodes,
                      &c->d_pool_base, &c->d_pool_size, &c->d_pool_top, &c->d_t_nins, &c->d_matA, &c->d_matD,
                      &c->d_matC, &c->d_cov, &c->d_gcount, &c->d_gbase, &c->d_bid, &c->d_nodes,
-                     &c->d_best, &c->d_queue, &c->d_score, &c->d_cns_tmp, &c->d_pool, &c->d_stk, &c->d_cuts, &c->d_bp_stat, &c->d_bp_len, &c->d_cns,
+                     &c->d_best, &c->d_queue, &c->d_score, &c->d_cns_tmp, &c->d_bp_tt, &c->d_pool, &c->d_stk, &c->d_cuts, &c->d_bp_stat, &c->d_bp_len, &c->d_cns,
                      &c->d_cns_off, &c->d_cns_len, &c->d_seg_first, &c->d_n_seg, &c->d_seg_r0, &c->d_seg_r1,
                      &c->d_st};
     for (DevBuf *b : all) free_buf(*b);

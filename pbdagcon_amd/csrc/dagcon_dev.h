@@ -135,7 +135,8 @@ struct DgParams {
     // ---- vertex arena ----
     DgNode *nodes;
     int32_t *best, *queue;
-    float2 *score;                 // (best-path score, edge-score term of the vertex as a target)
+    float2 *score;                 // (best-path score, 1 = final)
+    float *bp_tt;                  // per vertex: what an edge into it subtracts (k_bp_terms)
     uint8_t *cns_tmp;
     uint64_t node_cap;
     uint32_t *pool;

@@ -11,6 +11,7 @@
 //     w(e) = (float)count - coverage*0.5f       (the reference's left-to-right order)
 // that does not depend on any score.
 //
+//   k_bp_terms    thread per vertex: the target-side term of w(e), one float per vertex.
 //   k_bp_prepare  thread per vertex, whole chip: w(e) for every out edge, written over the
 //                 edge count in the out list (the counts are not needed any more).
 //   k_bp_sweep    one wave per (target, segment between two cut vertices of k_cuts); what
@@ -39,30 +40,48 @@
 #include <float.h>
 #include "dagcon_dev.h"
 
-__global__ __launch_bounds__(256) void k_bp_prepare(DgParams p) {
+// what an edge needs to know about its target t: -10 applies (backbone && weight == 1, :404-405),
+// else coverage[bbMap[t]] * 0.5f (:407-408).  One float per vertex, so that the per-edge pass
+// gathers 4 bytes from a compact array instead of the target's 32-byte record and its coverage.
+#define DG_TT_TEN 1.0e30f
+__global__ __launch_bounds__(256) void k_bp_terms(DgParams p) {
     const uint32_t t = blockIdx.x;
     if (dg_failed(p) || !p.tactive[t]) return;
     const uint64_t nb = p.node_base[t];
     const uint32_t N = p.n_nodes[t];
     const int32_t *cov = p.cov + p.bbv_base[t];
-    uint32_t *pool = p.pool + p.pool_base[t];
     const DgNode *nd = p.nodes + nb;
     for (uint32_t v = blockIdx.y * 256 + threadIdx.x; v < N; v += gridDim.y * 256) {
         const uint4 h = *reinterpret_cast<const uint4 *>(&nd[v]);
         const uint4 h2 = *(reinterpret_cast<const uint4 *>(&nd[v]) + 1);
-        const uint32_t out_len = h.x & 0xffffu;
-        for (uint32_t i = 0; i < out_len; i++) {
-            const uint32_t d = pool[h2.x + 2 * i];
-            const int cnt = (int)pool[h2.x + 2 * i + 1];
-            const uint4 dh = *reinterpret_cast<const uint4 *>(&nd[d]);
-            const uint4 dh2 = *(reinterpret_cast<const uint4 *>(&nd[d]) + 1);
-            float w;
-            if (((dh.y >> 8) & DG_NF_BACKBONE) && (int)dh.z == 1) w = -10.0f;     // :404-405
-            else w = (float)cnt - (float)cov[(int)dh2.w] * 0.5f;                  // :407-408
-            pool[h2.x + 2 * i + 1] = __float_as_uint(w);
-        }
+        float tt;
+        if (((h.y >> 8) & DG_NF_BACKBONE) && (int)h.z == 1) tt = DG_TT_TEN;
+        else tt = (float)cov[(int)h2.w] * 0.5f;
+        p.bp_tt[nb + v] = tt;
         p.score[nb + v] = make_float2(0.0f, 0.0f);     // (score, 1 = final); absent key reads as 0
         p.best[nb + v] = -1;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_bp_prepare(DgParams p) {
+    const uint32_t t = blockIdx.x;
+    if (dg_failed(p) || !p.tactive[t]) return;
+    const uint64_t nb = p.node_base[t];
+    const uint32_t N = p.n_nodes[t];
+    const float *tt = p.bp_tt + nb;
+    uint32_t *pool = p.pool + p.pool_base[t];
+    const DgNode *nd = p.nodes + nb;
+    for (uint32_t v = blockIdx.y * 256 + threadIdx.x; v < N; v += gridDim.y * 256) {
+        const uint32_t hx = *reinterpret_cast<const uint32_t *>(&nd[v]);
+        const uint32_t out_off = nd[v].out_off;
+        const uint32_t out_len = hx & 0xffffu;
+        for (uint32_t i = 0; i < out_len; i++) {
+            const uint32_t d = pool[out_off + 2 * i];
+            const int cnt = (int)pool[out_off + 2 * i + 1];
+            const float x = tt[d];
+            const float w = x == DG_TT_TEN ? -10.0f : (float)cnt - x;     // :404-408
+            pool[out_off + 2 * i + 1] = __float_as_uint(w);
+        }
     }
 }
 
