@@ -11,10 +11,12 @@
 //
 // Differences that are deliberate and documented in DESIGN.md:
 //   * output order is input order (the reference's is nondeterministic for -j >= 2, Q3);
-//   * -j is accepted and ignored (parallelism is the GPU's), -j 1 does not deadlock (Q2);
+//   * -j is the number of host threads that index the text and copy the strings (the consensus
+//     itself is the GPU's), -j 1 does not deadlock (Q2);
 //   * -a (re-align .pre input through blasr_libcpp) is refused: that library is absent;
 //   * blank lines are skipped (the reference duplicates the previous record, Q9);
 //   * a missing input file is an error on stderr, exit 1 (the reference is silent, Q11).
+#include <algorithm>
 #include <cerrno>
 #include <cstdint>
 #include <cstdio>
@@ -40,6 +42,7 @@ struct Opts {
     bool align = false, verbose = false, dump = false;
     size_t batch_targets = 256;        // small enough that parsing and the GPU overlap on mid-size inputs
     size_t batch_bytes = 1ull << 30;
+    size_t slab_bytes = 0;             // test hook: text indexed per round (0 = automatic)
     std::string input;
 };
 
@@ -48,7 +51,7 @@ void usage(FILE *f) {
             "USAGE: pbdagcon [-j <int>] [-c <uint>] [-m <uint>] [-t <uint>] [-a] [-v] <input>\n"
             "  PBDAGCON is a tool that implements DAGCon (Directed Acyclic Graph Consensus); this build\n"
             "  runs the consensus on an MI355X through libdagcon_hip.so.\n"
-            "  -j, --threads       accepted for compatibility (default 4)\n"
+            "  -j, --threads       host threads for parsing (default 4); the consensus runs on the GPU\n"
             "  -c, --min-coverage  minimum alignments per target, also the minimum node weight (default 6)\n"
             "  -m, --min-length    minimum alignment / consensus length (default 500)\n"
             "  -t, --trim          trim alignments on either side (default 50)\n"
@@ -82,6 +85,7 @@ int parse_args(int argc, char **argv, Opts &o) {
         else if (a == "-a" || a == "--align") o.align = true;
         else if (a == "-v" || a == "--verbose") o.verbose = true;
         else if (a == "--dump-parsed") o.dump = true;            // test hook: parser only, no GPU
+        else if (a == "--slab-bytes") { unsigned v = 0; if (!need(&v)) return 2; o.slab_bytes = v; }   // test hook
         else if (a == "-h" || a == "--help") { usage(stdout); exit(0); }
         else if (a == "--version") { printf("pbdagcon  version: 0.3\n"); exit(0); }
         else if (a == "-" || a[0] != '-') {
@@ -94,12 +98,10 @@ int parse_args(int argc, char **argv, Opts &o) {
 }
 
 // Alignment.cpp:15-26: only upper-case ACGT are complemented, then the string is reversed
-void revcomp_append(std::string &dst, const char *s, size_t n) {
-    size_t base = dst.size();
-    dst.resize(base + n);
+void revcomp_into(char *dst, const char *s, size_t n) {
     for (size_t i = 0; i < n; i++) {
         char c = s[n - 1 - i];
-        dst[base + i] = c == 'T' ? 'A' : c == 'G' ? 'C' : c == 'A' ? 'T' : c == 'C' ? 'G' : c;
+        dst[i] = c == 'T' ? 'A' : c == 'G' ? 'C' : c == 'A' ? 'T' : c == 'C' ? 'G' : c;
     }
 }
 
@@ -246,66 +248,179 @@ int main(int argc, char **argv) {
     };
 
     // ---- parse (Alignment.cpp:44-80) and group by target id (BlasrM5AlnProvider.cpp:34-55) ----
+    // 1. index: o.threads threads split the text at line starts and record where every field of
+    //    every record is (nothing is copied);
+    // 2. in file order: records are grouped into targets and targets into batches;
+    // 3. per batch the same threads copy (or reverse-complement) the strings into the blobs.
+    struct Rec {
+        const char *id, *name, *q, *t;
+        uint32_t idl, namel, len, tlen, start;
+        char strand;
+    };
+    struct Part { std::vector<Rec> recs; int err = 0; unsigned long long err_rec = 0; int err_nf = 0; };
+    const unsigned nthr = std::max(1u, std::min(o.threads, 64u));
+    // the text is taken a slab at a time, so that the first batch reaches the GPU before the
+    // whole file has been indexed; the records of a slab's last (possibly unfinished) target
+    // are carried into the next slab
+    const size_t slab_bytes = o.slab_bytes ? o.slab_bytes : std::max<size_t>(o.batch_bytes, 256u << 20);
+    size_t slab_pos = 0;
+    unsigned long long n_rec_before = 0;
+    bool had_error = false;
+    int status = 0;
+    std::vector<Rec> carry;
+    std::vector<Part> parts(nthr);
+    std::vector<const Rec *> recs;
+    auto index_slab = [&](size_t s0, size_t s1) {
+        std::vector<size_t> cut(nthr + 1, s1);
+        cut[0] = s0;
+        for (unsigned k = 1; k < nthr; k++) {
+            size_t p0 = std::max(cut[k - 1], s0 + (size_t)((unsigned long long)(s1 - s0) * k / nthr));
+            if (p0 > s0 && p0 < s1) {
+                const char *nl = (const char *)memchr(data + p0 - 1, '\n', s1 - (p0 - 1));
+                p0 = nl ? (size_t)(nl - data) + 1 : s1;
+            }
+            cut[k] = std::min(p0, s1);
+        }
+        auto index = [&](unsigned k) {
+            Part &pt = parts[k];
+            pt.recs.clear(); pt.err = 0;
+            size_t pos = cut[k];
+            const size_t stop = cut[k + 1];
+            while (pos < stop) {
+                const char *line = data + pos;
+                const char *nl = (const char *)memchr(line, '\n', size - pos);
+                size_t ll = nl ? (size_t)(nl - line) : size - pos;
+                pos += ll + (nl ? 1 : 0);
+                if (ll && line[ll - 1] == '\r') ll--;
+                const char *f[19];
+                size_t fl[19];
+                int nf = 0;
+                size_t i = 0;
+                while (i < ll && nf < 19) {
+                    while (i < ll && line[i] == ' ') i++;
+                    if (i >= ll) break;
+                    const char *sp = (const char *)memchr(line + i, ' ', ll - i);   // fields 16..18 are ~tlen chars each
+                    const size_t j = sp ? (size_t)(sp - line) : ll;
+                    f[nf] = line + i; fl[nf] = j - i; nf++;
+                    i = j;
+                }
+                if (nf == 0) continue;                          // blank line
+                if (nf < 19) { pt.err = 1; pt.err_rec = pt.recs.size() + 1; pt.err_nf = nf; return; }
+                if (fl[16] != fl[18]) { pt.err = 2; pt.err_rec = pt.recs.size() + 1; return; }
+                Rec r;
+                r.id = f[5]; r.idl = (uint32_t)fl[5];
+                r.name = f[0]; r.namel = (uint32_t)fl[0];
+                r.q = f[16]; r.t = f[18]; r.len = (uint32_t)fl[16];
+                r.tlen = tok_u32(f[6], fl[6]);
+                r.start = tok_u32(f[7], fl[7]) + 1;             // Alignment.cpp:65-66
+                r.strand = f[9][0];
+                pt.recs.push_back(r);
+            }
+        };
+        std::vector<std::thread> th;
+        for (unsigned k = 1; k < nthr; k++) th.emplace_back(index, k);
+        index(0);
+        for (auto &x : th) x.join();
+        // records in file order, up to the first malformed one
+        recs.clear();
+        for (const Rec &r : carry) recs.push_back(&r);
+        for (unsigned k = 0; k < nthr; k++) {
+            for (const Rec &r : parts[k].recs) recs.push_back(&r);
+            n_rec_before += parts[k].recs.size();
+            if (parts[k].err == 1) {
+                fprintf(stderr, "pbdagcon: format error: record %llu has %d fields, 19 expected\n", n_rec_before + 1, parts[k].err_nf);
+                had_error = true; break;
+            }
+            if (parts[k].err == 2) {
+                fprintf(stderr, "pbdagcon: format error: record %llu: query and target strings differ in length\n", n_rec_before + 1);
+                had_error = true; break;
+            }
+        }
+    };
+    // copies the strings of records [r0, r1) into batch b, whose offsets are set already
+    auto fill_strings = [&](Batch &b, size_t r0, size_t r1, size_t bytes) {
+        b.q.resize(bytes); b.t.resize(bytes);
+        auto work = [&](unsigned k) {
+            for (size_t x = r0 + k; x < r1; x += nthr) {
+                const Rec &r = *recs[x];
+                char *dq = &b.q[b.off[x - r0]], *dt = &b.t[b.off[x - r0]];
+                if (r.strand == '-') {                            // Alignment.cpp:69-75: start is NOT flipped (Q6)
+                    revcomp_into(dq, r.q, r.len);
+                    revcomp_into(dt, r.t, r.len);
+                } else {
+                    memcpy(dq, r.q, r.len);
+                    memcpy(dt, r.t, r.len);
+                }
+            }
+        };
+        std::vector<std::thread> th;
+        for (unsigned k = 1; k < nthr; k++) th.emplace_back(work, k);
+        work(0);
+        for (auto &x : th) x.join();
+    };
     Batch *bp = &bufs[0];
 #define b (*bp)
-    std::string cur_id;
-    bool have_group = false;
-    size_t pos = 0;
-    int status = 0;
-    unsigned long long n_rec = 0;
-    while (pos < size && status == 0) {
-        const char *line = data + pos;
-        const char *nl = (const char *)memchr(line, '\n', size - pos);
-        size_t ll = nl ? (size_t)(nl - line) : size - pos;
-        pos += ll + (nl ? 1 : 0);
-        if (ll && line[ll - 1] == '\r') ll--;
-        const char *f[19];
-        size_t fl[19];
-        int nf = 0;
-        size_t i = 0;
-        while (i < ll && nf < 19) {
-            while (i < ll && line[i] == ' ') i++;
-            if (i >= ll) break;
-            const char *sp = (const char *)memchr(line + i, ' ', ll - i);      // fields 16..18 are ~tlen chars each
-            const size_t j = sp ? (size_t)(sp - line) : ll;
-            f[nf] = line + i; fl[nf] = j - i; nf++;
-            i = j;
+    while (status == 0 && !had_error && (slab_pos < size || !carry.empty())) {
+        size_t s1 = std::min(size, slab_pos + slab_bytes);
+        if (s1 < size) {                                   // a slab ends at a line end
+            const char *nl = (const char *)memchr(data + s1, '\n', size - s1);
+            s1 = nl ? (size_t)(nl - data) + 1 : size;
         }
-        if (nf == 0) continue;                          // blank line
-        if (nf < 19) { fprintf(stderr, "pbdagcon: format error: record %llu has %d fields, 19 expected\n", n_rec + 1, nf); status = 1; break; }
-        n_rec++;
-        if (fl[16] != fl[18]) { fprintf(stderr, "pbdagcon: format error: record %llu: query and target strings differ in length\n", n_rec); status = 1; break; }
-        const bool new_target = !have_group || cur_id.size() != fl[5] || memcmp(cur_id.data(), f[5], fl[5]) != 0;
-        if (new_target) {
-            if (have_group) b.begin.push_back(b.start.size());
-            if (b.ids.size() >= o.batch_targets || b.q.size() >= o.batch_bytes) {
-                if (o.dump) b.clear();
-                else { status = submit(); bp = &bufs[fill]; }
-                if (status) break;
+        index_slab(slab_pos, s1);
+        slab_pos = s1;
+        const bool eof = slab_pos >= size || had_error;
+        // all but the last target of the slab (it may go on in the next one)
+        size_t n_use = recs.size();
+        if (!eof) {
+            while (n_use > 0 && recs[n_use - 1]->idl == recs.back()->idl &&
+                   memcmp(recs[n_use - 1]->id, recs.back()->id, recs.back()->idl) == 0) n_use--;
+        }
+        size_t rb = 0;                                   // first record of the batch being formed
+        size_t bytes = 0;
+        for (size_t x = 0; x <= n_use && status == 0; x++) {
+            const bool last = x == n_use;
+            const bool new_target = !last && (x == rb || recs[x]->idl != recs[x - 1]->idl ||
+                                              memcmp(recs[x]->id, recs[x - 1]->id, recs[x]->idl) != 0);
+            // a batch is closed when it is full, and at the end of the slab's usable records once it
+            // holds something (at the end of the input whatever it holds)
+            if (last || (new_target && x > rb && (b.ids.size() >= o.batch_targets || bytes >= o.batch_bytes))) {
+                if (x > rb) {
+                    b.begin.push_back(b.start.size());
+                    fill_strings(b, rb, x, bytes);
+                    if (o.dump) {
+                        for (size_t y = rb; y < x; y++) {
+                            const Rec &r = *recs[y];
+                            const size_t o0 = b.off[y - rb];
+                            size_t g = 0;
+                            while (b.begin[g + 1] <= y - rb) g++;
+                            printf("%.*s\t%u\t%u\t%c\t%.*s\t%.*s\t%.*s\n", (int)r.idl, r.id, b.tlen[g], r.start, r.strand,
+                                   (int)r.namel, r.name, (int)r.len, b.q.data() + o0, (int)r.len, b.t.data() + o0);
+                        }
+                        b.clear();
+                    } else { status = submit(); bp = &bufs[fill]; }
+                }
+                rb = x; bytes = 0;
+                if (last || status) break;
             }
-            cur_id.assign(f[5], fl[5]);
-            b.ids.push_back(cur_id);
-            b.tlen.push_back(tok_u32(f[6], fl[6]));
-            have_group = true;
+            const Rec &r = *recs[x];
+            if (new_target) {
+                if (x > rb) b.begin.push_back(b.start.size());
+                b.ids.emplace_back(r.id, r.idl);
+                b.tlen.push_back(r.tlen);
+            }
+            b.start.push_back(r.start);
+            b.off.push_back(bytes);
+            b.len.push_back(r.len);
+            bytes += r.len;
         }
-        const uint32_t start = tok_u32(f[7], fl[7]) + 1;   // Alignment.cpp:65-66
-        const char strand = f[9][0];
-        b.start.push_back(start);
-        b.off.push_back(b.q.size());
-        b.len.push_back((uint32_t)fl[16]);
-        if (strand == '-') {                               // Alignment.cpp:69-75: start is NOT flipped (Q6)
-            revcomp_append(b.q, f[16], fl[16]);
-            revcomp_append(b.t, f[18], fl[18]);
-        } else {
-            b.q.append(f[16], fl[16]);
-            b.t.append(f[18], fl[18]);
-        }
-        if (o.dump) {
-            const size_t o0 = b.off.back();
-            printf("%.*s\t%u\t%u\t%c\t%.*s\t%.*s\t%.*s\n", (int)fl[5], f[5], b.tlen.back(), start, strand,
-                   (int)fl[0], f[0], (int)fl[16], b.q.data() + o0, (int)fl[18], b.t.data() + o0);
-        }
+        // the unfinished target's records wait for the next slab
+        std::vector<Rec> next_carry;
+        for (size_t x = n_use; x < recs.size(); x++) next_carry.push_back(*recs[x]);
+        carry.swap(next_carry);
+        if (eof && carry.empty()) break;
+        if (eof) slab_pos = size;
     }
+    if (had_error) status = 1;
 #undef b
     if (!o.dump) {
         if (status == 0) status = submit();

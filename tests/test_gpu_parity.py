@@ -468,6 +468,9 @@ def test_cli_end_to_end(tmp_path):
     assert out.stdout == b"".join(exp) and len(exp) == 4
     out2 = subprocess.run([cli, "-"], input=m5, capture_output=True, timeout=300)
     assert out2.returncode == 0 and out2.stdout == out.stdout
+    # several batches in flight (a new batch per slab of text), targets carried across slab edges
+    out3 = subprocess.run([cli, "-j", "3", "--slab-bytes", "20000", str(path)], capture_output=True, timeout=300)
+    assert out3.returncode == 0 and out3.stdout == out.stdout
 
 
 def test_config3_and_config5_shapes(gpu_ctx_factory):

@@ -138,6 +138,12 @@ def test_cli_parser_matches_reference_parser(tmp_path):
         e = oracle.parse_m5(ln.encode(), True)
         assert g == [e["id"].decode(), str(e["tlen"]), str(e["start"]), e["strand"].decode(),
                      e["sid"].decode(), e["qstr"].decode(), e["tstr"].decode()]
+    # the text is indexed a slab at a time by -j threads; a target that straddles slab edges is
+    # carried over: tiny slabs, odd thread counts, same lines out
+    for slab, j in ((200, 3), (1000, 1), (5000, 7)):
+        out2 = subprocess.run([_cli(), "--dump-parsed", "--slab-bytes", str(slab), "-j", str(j), str(path)],
+                              capture_output=True, text=True, timeout=60)
+        assert out2.returncode == 0 and out2.stdout == out.stdout, (slab, j)
     assert got[0][5:] == ["CAC", "CGC"] and got[1][5:] == ["AATTGGCC", "GGCCAATT"]   # AlignmentTest.cpp:49-63
 
 

@@ -26,7 +26,7 @@ print(f"wrote {size / 1e6:.1f} MB of .m5 in {time.time() - t0:.1f} s", flush=Tru
 exe = os.path.join(ROOT, "pbdagcon_amd", "bin", "pbdagcon")
 for rep in range(2):
     t0 = time.time()
-    out = subprocess.run([exe, "-j", "1", path], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    out = subprocess.run([exe, "-j", os.environ.get("E2E_J", "8"), path], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     dt = time.time() - t0
     bases = sum(len(l) for l in out.stdout.split(b"\n") if l and not l.startswith(b">"))
     print(f"run {rep}: rc {out.returncode}, {dt:.2f} s wall, {bases} consensus bases, "
