@@ -190,10 +190,23 @@ __device__ __forceinline__ void dg_bp_sweep(DgBpShared &S, const DgNode *nd, int
         // (lens, edges) of the next vertex are read one step ahead: their LDS latency overlaps
         // the current step
         const int el = lane < DG_BOUT ? lane : 0;
-        int pf_ln = S.lens[v_hi & (DG_BR - 1)];
-        int pf_d = S.out_dst[(v_hi & (DG_BR - 1)) * DG_BOUT + el];
-        float pf_w = S.out_w[(v_hi & (DG_BR - 1)) * DG_BOUT + el];
-        for (int v = v_hi; v >= v_lo && !bad; v--) {
+        // the vertices of the chunk that are still in the graph (lane l <-> vertex v_hi - l): the
+        // ~40 % the merge deleted are never looked at
+        unsigned long long live;
+        {
+            const int vl = v_hi - lane;
+            const int lnl = vl >= v_lo ? S.lens[vl & (DG_BR - 1)] : (int)DG_BL_DONE;
+            live = __ballot(!(lnl & DG_BL_DONE) && !((lnl >> 16) & DG_NF_DELETED));
+        }
+        int pf_ln = 0, pf_d = 0;
+        float pf_w = 0.0f;
+        if (live) {
+            const int x0 = (v_hi - (__ffsll((long long)live) - 1)) & (DG_BR - 1);
+            pf_ln = S.lens[x0]; pf_d = S.out_dst[x0 * DG_BOUT + el]; pf_w = S.out_w[x0 * DG_BOUT + el];
+        }
+        while (live && !bad) {
+            const int v = v_hi - (__ffsll((long long)live) - 1);
+            live &= live - 1ull;
             // ---- straight-line step for the common case: the vertex of the stream is staged,
             // its edges fit the slot and every successor already has its score in the ring.
             // Two LDS trips: (lens, edges) then (successor scores). ----
@@ -202,11 +215,11 @@ __device__ __forceinline__ void dg_bp_sweep(DgBpShared &S, const DgNode *nd, int
                 const int ln = __builtin_amdgcn_readfirstlane(pf_ln);          // chunk c is resident: tag == v
                 const int d = pf_d;
                 const float w = pf_w;
-                if (v > v_lo) {
-                    const int xn = (v - 1) & (DG_BR - 1);
+                if (live) {
+                    const int xn = (v_hi - (__ffsll((long long)live) - 1)) & (DG_BR - 1);
                     pf_ln = S.lens[xn]; pf_d = S.out_dst[xn * DG_BOUT + el]; pf_w = S.out_w[xn * DG_BOUT + el];
                 }
-                if ((ln & DG_BL_DONE) || ((ln >> 16) & DG_NF_DELETED)) continue;
+                if (ln & DG_BL_DONE) continue;                                  // scored early, as somebody's successor
                 if (!(ln & DG_BL_HBM)) {
                     const int ol = ln & 0xffff;
                     const int y = d & (DG_SR - 1);
