@@ -94,7 +94,9 @@ __global__ __launch_bounds__(256) void k_bp_prepare(DgParams p) {
 #endif
 #define DG_BR 64             // staged vertices (id & 63): the chunk being swept
 #define DG_WR 256            // the walk's staging ring
-#define DG_BSTK 64           // vertices waiting for a successor's score
+#define DG_BSTK 64           // evaluation stack (LDS part)
+#define DG_BDEF 32           // vertices that wait for a far successor (def_v: who, def_b: for whom)
+#define DG_BFAR 192          // a successor this many ids below the stream is "far"
 #define DG_BL_HBM  0x40000000  // lens: the edges did not fit the slot
 #define DG_BL_DONE 0x20000000  // lens: scored already
 
@@ -106,6 +108,7 @@ struct DgBpShared {
     int out_dst[DG_BR * DG_BOUT];
     float out_w[DG_BR * DG_BOUT];
     int stk[DG_BSTK];
+    int def_v[DG_BDEF], def_b[DG_BDEF];
     int rbest[DG_BR];
     float rscore[DG_BR];                 // results of the chunk being swept, flushed at its end
 };
@@ -176,6 +179,34 @@ __device__ __forceinline__ void dg_bp_sweep(DgBpShared &S, const DgNode *nd, int
 
     unsigned long long guard = 0;
     const unsigned long long guard_max = 64ull * (unsigned long long)(v_top - v_bot + 1) + 1000000ull;
+
+    // A successor FAR below the stream (partial-span reads: the vertices merged at `enter` reach all
+    // over the backbone) is not chased: that would score everything in between on the slow path
+    // below.  The vertex WAITS for it instead (so does every vertex on the evaluation stack under
+    // it), the stream goes on, and when the successor has its score the waiting vertex is looked at
+    // again.  Few vertices ever wait (DG_BDEF; the stack takes over when the list is full).
+    int ndef = 0;
+    // x has its score now: the vertices that wait for it go onto the evaluation stack (entries
+    // q0, q0+1, ...; entry q lives in S.stk[q] or, beyond DG_BSTK, in the HBM scratch) and leave
+    // the waiting list.  Returns how many.
+    auto collect = [&](const int x, const int q0) -> int {
+        const bool in = lane < ndef;
+        const int wv = in ? S.def_v[lane] : 0, wb = in ? S.def_b[lane] : -1;
+        const unsigned long long hit = __ballot(in && wb == x);
+        if (!hit) return 0;
+        const unsigned long long below = (1ull << lane) - 1ull;
+        if ((hit >> lane) & 1ull) {
+            const int q = q0 + __popcll(hit & below);
+            if (q < DG_BSTK) S.stk[q] = wv; else gstk[q - DG_BSTK] = wv;
+        } else if (in) {
+            const unsigned long long stay = __ballot(in) & ~hit;       // (same value in every lane)
+            const int k = __popcll(stay & below);
+            S.def_v[k] = wv; S.def_b[k] = wb;
+        }
+        ndef -= __popcll(hit);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        return __popcll(hit);
+    };
     for (int c = 0; c < n_chunks && !bad; c++) {
         if (c > 0) {
             // chunk c: its records and edges were requested a whole chunk ago
@@ -210,6 +241,7 @@ __device__ __forceinline__ void dg_bp_sweep(DgBpShared &S, const DgNode *nd, int
             // ---- straight-line step for the common case: the vertex of the stream is staged,
             // its edges fit the slot and every successor already has its score in the ring.
             // Two LDS trips: (lens, edges) then (successor scores). ----
+            int woken = 0;
             {
                 const int xs = v & (DG_BR - 1);
                 const int ln = __builtin_amdgcn_readfirstlane(pf_ln);          // chunk c is resident: tag == v
@@ -245,14 +277,15 @@ __device__ __forceinline__ void dg_bp_sweep(DgBpShared &S, const DgNode *nd, int
                             S.lens[xs] = ln | DG_BL_DONE;
                         }
                         amax = fmaxf(amax, fabsf(mx));
-                        continue;
+                        if (ndef) woken = collect(v, 0);          // (rare: somebody far above waits for v)
+                        if (!woken) continue;
                     }
                 }
             }
             // ---- general step: the vertex of the stream is the bottom of the evaluation stack
-            // and stays in a register; entries above it (turned-around edges only) live in LDS,
-            // then HBM ----
-            int sp = 1;
+            // and stays in a register; entries above it (turned-around edges, vertices that
+            // waited) live in LDS, then HBM ----
+            int sp = 1 + woken;
             while (sp > 0) {
                 // every wave must leave this loop: the work is bounded by (vertices + edges), far
                 // below this budget; running out of it means a broken graph, not a long one
@@ -312,6 +345,25 @@ __device__ __forceinline__ void dg_bp_sweep(DgBpShared &S, const DgNode *nd, int
                     }
                     const unsigned long long miss = __ballot(valid && !have);
                     if (miss) {
+                        const unsigned long long far = __ballot(valid && !have && d < v - DG_BFAR);
+                        if (far && ndef + sp <= DG_BDEF) {
+                            // n waits for its far successor, every entry under it for the entry above
+                            const int dfar = __builtin_amdgcn_readlane(d, __ffsll((long long)far) - 1);
+                            int above = dfar;
+                            for (int q = sp - 1; q >= 0; q--) {
+                                int who;
+                                if (q == 0) who = v;
+                                else if (q - 1 < DG_BSTK) who = __builtin_amdgcn_readfirstlane(S.stk[q - 1]);
+                                else who = __builtin_amdgcn_readfirstlane(gstk[q - 1 - DG_BSTK]);
+                                if (lane == 0) { S.def_v[ndef] = who; S.def_b[ndef] = above; }
+                                ndef++;
+                                above = who;
+                            }
+                            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                            sp = 0;
+                            again = true;
+                            break;
+                        }
                         // turned-around edges: score those successors first, then come back
                         if (sp + __popcll(miss) > DG_BSTK + gstk_cap) { bad = true; break; }
                         if (valid && !have) {
@@ -336,7 +388,7 @@ __device__ __forceinline__ void dg_bp_sweep(DgBpShared &S, const DgNode *nd, int
                 if (lane == 0) {
                     S.stag[n & (DG_SR - 1)] = n;
                     S.sval[n & (DG_SR - 1)] = mx;
-                    if (in_ring && n >= v_lo) {            // this chunk: HBM gets it at the end of the chunk
+                    if (in_ring && n >= v_lo && n <= v_hi) {   // this chunk: HBM gets it at the end of the chunk
                         S.rscore[x] = mx; S.rbest[x] = bd;
                         S.lens[x] = lens | DG_BL_DONE;
                     } else {
@@ -349,6 +401,12 @@ __device__ __forceinline__ void dg_bp_sweep(DgBpShared &S, const DgNode *nd, int
                 // same successors, same result)
                 amax = fmaxf(amax, fabsf(mx));
                 sp--;
+                if (ndef) {                                // those that waited for n are next
+                    if (sp + 1 + ndef > DG_BSTK + gstk_cap) { bad = true; break; }
+                    const int base = sp > 0 ? sp : 1;      // (the finished stream vertex stays the bottom)
+                    const int k = collect(n, base - 1);
+                    if (k) sp = base + k;
+                }
             }
         }
         // the chunk's results leave as two row stores
