@@ -1,0 +1,53 @@
+"""Randomised parity campaign against the oracle (checker), larger than the test suite: mixed
+lengths, coverages, alphabets, spans, trims, segment / stretch settings."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+from pbdagcon_amd import capi, synth
+from util import batch_from_targets, oracle_batch, random_target
+
+seed0 = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+bad = 0
+for rnd in range(rounds):
+    rng = np.random.default_rng(seed0 * 1000 + rnd)
+    t0 = time.time()
+    if rnd % 2 == 0:
+        # generator-made pileups: mixed lengths, partial spans
+        n = int(rng.integers(8, 40))
+        tl = rng.integers(600, 9000, n)
+        span = float(rng.choice([1.0, 0.9, 0.6, 0.3]))
+        cov = int(rng.integers(8, 70))
+        b = synth.make_batch(n, 0, cov, seed=int(rng.integers(1, 1 << 30)), min_span=span, tlens=tl,
+                             with_backbone=bool(rng.integers(0, 2)))
+        desc = f"synth n={n} cov={cov} span={span}"
+    else:
+        # adversarial: small alphabets, high indel rates
+        targets = []
+        for i in range(int(rng.integers(5, 25))):
+            tl = int(rng.integers(300, 4000))
+            alph = [b"AC", b"ACGT", b"A", b"ACGTN"][int(rng.integers(0, 4))]
+            alns, bb = random_target(rng, tl, int(rng.integers(2, 30)), alphabet=alph, sub=float(rng.uniform(0, 0.1)),
+                                     ins=float(rng.uniform(0.02, 0.3)), dele=float(rng.uniform(0.02, 0.3)),
+                                     ins_ext=float(rng.uniform(0.1, 0.6)), full_span=bool(rng.integers(0, 2)))
+            targets.append((tl, alns, bb))
+        b = batch_from_targets(targets, with_backbone=bool(rng.integers(0, 2)))
+        desc = f"adversarial n={len(targets)}"
+    min_cov = int(rng.choice([0, 2, 6]))
+    min_len = int(rng.choice([0, 50, 500]))
+    trim = int(rng.choice([0, 1, 10, 50, 300]))
+    exp = oracle_batch(b, min_cov, min_len, trim)
+    for kw in (dict(), dict(max_segments=1), dict(max_segments=64, min_segment_len=int(rng.choice([4, 64, 300])))):
+        for shift in (None, "4", "6"):
+            if shift is None: os.environ.pop("DAGCON_EMIT_SHIFT", None)
+            else: os.environ["DAGCON_EMIT_SHIFT"] = shift
+            ctx = capi.Context(min_cov=min_cov, min_len=min_len, trim=trim, **kw)
+            got = ctx.consensus(b)
+            ctx.close()
+            if got != exp:
+                bad += 1
+                print("MISMATCH", desc, kw, shift, min_cov, min_len, trim, flush=True)
+    print(f"round {rnd}: {desc} -c {min_cov} -m {min_len} -t {trim}: ok ({time.time() - t0:.1f} s)", flush=True)
+print("mismatches:", bad)
+sys.exit(1 if bad else 0)
