@@ -64,6 +64,7 @@ struct Ctx {
 
     uint64_t norm_cap = 0, node_cap = 0, pool_cap = 0, cns_cap = 0, seg_cap = 0;
     uint32_t stk_words = 16384, growth_pct = 100, seg_max = 8, seg_env = 0;
+    uint64_t expected_workers = 0;                  // merge workers the batch will probably run (prefetch on / off)
 
     DgStatus h_st;
     dagcon_timings tm;
@@ -195,7 +196,7 @@ void fill_params(Ctx *c, DgParams &p) {
     p.stk = (int32_t *)c->d_stk.p; p.stk_words = c->stk_words; p.growth_pct = c->growth_pct;
     // the prefetch wave pays while the chip has idle wave slots; past ~1.5 workers per SIMD the
     // workers hide each other's latency and it only takes issue slots from them
-    { const char *e = getenv("DAGCON_PF_AHEAD"); p.pf_ahead = e ? (uint32_t)atoi(e) : ((uint64_t)c->T * c->seg_max >= 1536 ? 0u : 48u); }
+    { const char *e = getenv("DAGCON_PF_AHEAD"); p.pf_ahead = e ? (uint32_t)atoi(e) : (c->expected_workers >= 4096 ? 0u : 48u); }
     p.seg_max = c->seg_max; p.seg_min = c->opts.min_segment_len ? c->opts.min_segment_len : 768u; p.cuts = (uint32_t *)c->d_cuts.p; p.bp_stat = (float *)c->d_bp_stat.p; p.bp_len = (uint32_t *)c->d_bp_len.p;
     p.cns = (uint8_t *)c->d_cns.p; p.cns_cap = c->cns_cap;
     p.cns_off = (uint64_t *)c->d_cns_off.p; p.cns_len = (uint32_t *)c->d_cns_len.p;
@@ -362,7 +363,7 @@ int dagcon_upload(dagcon_ctx *ctx, const dagcon_batch *b) {
     c->h_aln_len.clear(); c->h_aln_start.clear(); c->h_aln_tgt.clear(); c->h_aln_off.clear();
     c->max_k = 0; c->max_tlen = 0; c->sum_len = 0; c->sum_bb = 0; c->mat_cells = 0;
     c->have_bb = b->backbone != nullptr;
-    uint64_t bb_bytes = 0;
+    uint64_t bb_bytes = 0, n_full = 0;
     const uint64_t min_cov = c->opts.min_cov;
     for (uint32_t t = 0; t < T; t++) {
         const uint64_t ab = b->aln_begin[t], ae = b->aln_begin[t + 1];
@@ -384,6 +385,7 @@ int dagcon_upload(dagcon_ctx *ctx, const dagcon_batch *b) {
             c->h_aln_off.push_back(b->aln_off[a]);
             c->h_aln_tgt.push_back(t);
             c->sum_len += len;
+            n_full += (uint64_t)len * 10 >= (uint64_t)b->tlen[t] * 9;    // the strings cover (nearly) the whole target
         }
         const uint64_t k = c->h_aln_len.size() - c->h_aln_begin[t];
         if (k > DAGCON_MAX_COVERAGE)
@@ -406,6 +408,9 @@ int dagcon_upload(dagcon_ctx *ctx, const dagcon_batch *b) {
     if (c->h_aln_len.size() > 0xFFFFFFF0ull) return fail(c, DAGCON_ERR_UNSUPPORTED, "too many alignments");
     c->A = (uint32_t)c->h_aln_len.size();
     c->blob_bytes = b->blob_bytes;
+    // cut vertices need every read to span them: with full-span reads a target is swept in seg_max
+    // pieces, with partial spans in a few
+    c->expected_workers = n_full * 10 >= (uint64_t)c->A * 9 ? (uint64_t)T * c->seg_max : (uint64_t)T * 3;
     // windows of DG_NCH input columns: the units of the chunked normalizeGaps
     c->h_ch_base.assign((size_t)c->A + 1, 0);
     c->h_ch_aln.clear();
