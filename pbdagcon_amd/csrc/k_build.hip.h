@@ -601,6 +601,8 @@ __global__ __launch_bounds__(1024) void k_carve(DgParams p) {
             nodes = (unsigned long long)p.tlen[t] + 2ull + ins;
             if (nodes > DG_MAX_NODES) { dg_fail(p, DG_E_TOO_BIG); p.st->bad_target = t; }
             poolw = dg_pool_words(p.tlen[t], ins, del, (uint32_t)(e - b), p.growth_pct, &fixed_words);
+            // (the sweeps address a target's pool with 32-bit byte offsets)
+            if (poolw > 0x3FFFFFFFull) { dg_fail(p, DG_E_TOO_BIG); p.st->bad_target = t; }
         }
         s_scan[tid] = nodes;
         __syncthreads();
@@ -787,6 +789,10 @@ __global__ __launch_bounds__(64) void k_emit(DgParams p) {
     uint32_t *Dm = p.matD + p.mat_base[t];
     const uint32_t *Cm = p.matC + p.mat_base[t];
     uint32_t *pool = p.pool + p.pool_base[t];
+    DgNode *ndt = p.nodes + nb;
+    // pool words / vertex records / matrix cells: uniform base + 32-bit byte offset (see k_merge)
+#define DG_EPW(OFF) (*reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(pool) + (((uint32_t)(OFF)) << 2)))
+#define DG_ECELL(M, POS) (*reinterpret_cast<uint32_t *>(reinterpret_cast<char *>((M) + (uint64_t)(POS) * K) + (r << 2)))
     const uint16_t *buf = p.norm + p.norm_off[a];
     const uint32_t lo = done ? 0 : p.n_lo[a], hi = done ? 0 : p.n_hi[a];
     uint32_t bbpos = done ? 0xFFFFFFFFu : p.n_start[a];
@@ -851,11 +857,11 @@ __global__ __launch_bounds__(64) void k_emit(DgParams p) {
         if (!own) break;                                                     \
         if (prev_bb) {                                                       \
             if (prev_pos >= pos0) s_D[(prev_pos - pos0) * 64 + lane] = (NXT) + 1u;   \
-            else Dm[(uint64_t)prev_pos * K + r] = (NXT) + 1u;                \
+            else DG_ECELL(Dm, prev_pos) = (NXT) + 1u;                \
         } else {                                                             \
             const uint32_t _rk = prev - prev_pos;                            \
-            pool[3u * _rk] = (NXT);                                          \
-            pool[3u * _rk + 1u] = 1u;                                        \
+            DG_EPW(3u * _rk) = (NXT);                                        \
+            DG_EPW(3u * _rk + 1u) = 1u;                                      \
         }                                                                    \
     } while (0)
 
@@ -884,7 +890,7 @@ __global__ __launch_bounds__(64) void k_emit(DgParams p) {
             }
 #pragma unroll
             for (int j = 0; j < DG_EB; j++)
-                cmv[j] = (!done && pos0 + j <= exitpos) ? Cm[(uint64_t)(pos0 + j) * K + r] : 0u;
+                cmv[j] = (!done && pos0 + j <= exitpos) ? DG_ECELL(const_cast<uint32_t *>(Cm), pos0 + j) : 0u;
         }
         if (!done && i < hi && (i - c_base) + 24u > DG_ECOLS) DG_STAGE(i);
         uint32_t acell[DG_EB];
@@ -914,8 +920,8 @@ __global__ __launch_bounds__(64) void k_emit(DgParams p) {
                         nd.weight = 1; nd.pending = 1;
                         nd.out_off = 3u * rk; nd.in_off = 3u * rk + 2u; nd.out_cap = 1; nd.in_cap = 1;
                         nd.bbpos = (int32_t)bbpos;
-                        p.nodes[nb + id] = nd;
-                        pool[3u * rk + 2u] = prev;
+                        *reinterpret_cast<DgNode *>(reinterpret_cast<char *>(ndt) + (id << 5)) = nd;
+                        DG_EPW(3u * rk + 2u) = prev;
                         DG_DEPART(id);
                         prev = id; prev_pos = bbpos; prev_bb = false; own = true;
                     }
@@ -949,14 +955,14 @@ __global__ __launch_bounds__(64) void k_emit(DgParams p) {
             for (int j = 0; j < DG_EB; j++) {
                 const uint32_t pos = pos0 + j;
                 if (pos <= blen && pos >= P0 && pos < P1) {
-                    Am[(uint64_t)pos * K + r] = acell[j];
+                    DG_ECELL(Am, pos) = acell[j];
                     // (the enter vertex's row is shared: a read that starts in a later stretch
                     // has its cell written by that stretch's wave)
                     const uint32_t dv = s_D[j * 64 + lane];
-                    if (pos > 0 || dv) Dm[(uint64_t)pos * K + r] = dv;
+                    if (pos > 0 || dv) DG_ECELL(Dm, pos) = dv;
                 }
             }
-            if (exit_cell) Am[(uint64_t)exitpos * K + r] = exit_val;
+            if (exit_cell) DG_ECELL(Am, exitpos) = exit_val;
         }
         pos0 += DG_EB;
     }
@@ -980,6 +986,8 @@ __global__ __launch_bounds__(64) void k_emit(DgParams p) {
         const uint32_t pos0 = 0xFFFFFFFFu;                // no row of this departure is staged any more
         DG_DEPART(nxt);
     }
+#undef DG_EPW
+#undef DG_ECELL
 #undef DG_DEPART
 #undef DG_COLUMN
 #undef DG_STAGE

@@ -365,6 +365,11 @@ __device__ inline void dg_prefetch_wave(const DgNode *nd, const uint32_t *pool, 
 // Wave-cooperative merge.  Everything below is executed by all 64 lanes with
 // wave-uniform control flow; a lane holds one list entry.
 // ============================================================================
+// pool word / vertex record through a 32-bit BYTE offset from the (wave-uniform) base: the
+// compiler can then address with the base in an SGPR pair and the offset in one VGPR instead of
+// building a 64-bit address per lane (a target's pool is < 2^30 words, its ids < 2^25)
+#define DG_PW(G, OFF) (*reinterpret_cast<uint32_t *>(reinterpret_cast<char *>((G).pool) + (((uint32_t)(OFF)) << 2)))
+#define DG_NV(G, V) (*reinterpret_cast<DgNode *>(reinterpret_cast<char *>((G).nd) + (((uint32_t)(V)) << 5)))
 #define DG_LT(lane) ((1ull << (lane)) - 1ull)
 // orders this wave's earlier stores (a single lane's, on the literal path) before its
 // later loads; the worker is one wave, so no s_barrier is involved
@@ -436,12 +441,12 @@ __device__ __forceinline__ uint32_t dg_wave_alloc(DgGraph &g, uint32_t words, in
 // Requires in_len(v) <= 64.
 __device__ inline void dgw_in_rewrite(DgGraph &g, int v, int vid, unsigned long long vm, int app,
                                       int pend_delta, int lane) {
-    const uint4 h = dg_lo16(&g.nd[v]), h2 = dg_hi16(&g.nd[v]);
+    const uint4 h = dg_lo16(&DG_NV(g, v)), h2 = dg_hi16(&DG_NV(g, v));
     const int len = DG_H_INLEN(h);
     uint32_t off = DG_H2_INOFF(h2);
     int cap = DG_H2_INCAP(h2);
     int e = -1;
-    if (lane < len) e = (int)g.pool[off + lane];
+    if (lane < len) e = (int)DG_PW(g, off + lane);
     bool rm = false;
     for (unsigned long long m = vm; m; m &= m - 1ull) rm |= (e == DG_RL(vid, __ffsll((long long)m) - 1));
     const bool keep = lane < len && !rm;
@@ -455,10 +460,10 @@ __device__ inline void dgw_in_rewrite(DgGraph &g, int v, int vid, unsigned long 
         if (noff == 0xFFFFFFFFu) return;
         off = noff; cap = (int)ncap;
     }
-    if (keep) g.pool[off + nidx] = (uint32_t)e;
-    if (app >= 0) { if (lane == 0) g.pool[off + nlen] = (uint32_t)app; nlen++; }
+    if (keep) DG_PW(g, off + nidx) = (uint32_t)e;
+    if (app >= 0) { if (lane == 0) DG_PW(g, off + nlen) = (uint32_t)app; nlen++; }
     if (lane == 0) {
-        DgNode *n = &g.nd[v];
+        DgNode *n = &DG_NV(g, v);
         n->in_len = (uint16_t)nlen; n->in_off = off; n->in_cap = (uint16_t)cap;
         if (pend_delta) n->pending = DG_H_PEND(h) + pend_delta;
     }
@@ -475,7 +480,7 @@ __device__ inline bool dgw_merge_out_group(DgGraph &g, int u, const DgNode &nu, 
     const int an = DG_RL(d, an_lane);
     const bool member = (M >> lane) & 1ull;
     uint4 h2 = make_uint4(0, 0, 0, 0);
-    if (member) h2 = dg_hi16(&g.nd[d]);
+    if (member) h2 = dg_hi16(&DG_NV(g, d));
     // members' out entries flattened onto lanes 0..L-1: survivor's first, then victims in order
     int L = 0, src = -1, e = 0;
     uint32_t src_off = 0;
@@ -493,10 +498,10 @@ __device__ inline bool dgw_merge_out_group(DgGraph &g, int u, const DgNode &nu, 
     if (L > 64) return false;
     const bool fl = lane < L;
     int n2 = -1, c2 = 0;
-    if (fl) { n2 = (int)g.pool[src_off + 2 * e]; c2 = (int)g.pool[src_off + 2 * e + 1]; }
+    if (fl) { n2 = (int)DG_PW(g, src_off + 2 * e); c2 = (int)DG_PW(g, src_off + 2 * e + 1); }
     const bool vic_entry = fl && src != an_lane;
     uint4 hn2 = make_uint4(0, 0, 0, 0);
-    if (vic_entry) hn2 = dg_lo16(&g.nd[n2]);
+    if (vic_entry) hn2 = dg_lo16(&DG_NV(g, n2));
     if (__ballot(vic_entry && DG_H_INLEN(hn2) > 64)) return false;
 
     // ---- nothing has been modified up to here ----
@@ -536,12 +541,12 @@ __device__ inline bool dgw_merge_out_group(DgGraph &g, int u, const DgNode &nu, 
         }
         if ((first_m >> lane) & 1ull) {
             const int idx = __popcll(first_m & DG_LT(lane));
-            g.pool[off + 2 * idx] = (uint32_t)n2;
-            g.pool[off + 2 * idx + 1] = (uint32_t)newcnt;
+            DG_PW(g, off + 2 * idx) = (uint32_t)n2;
+            DG_PW(g, off + 2 * idx + 1) = (uint32_t)newcnt;
         }
         const int an_w = DG_RL(DG_H_WEIGHT(h), an_lane);
         if (lane == 0) {
-            DgNode *a = &g.nd[an];
+            DgNode *a = &DG_NV(g, an);
             a->out_len = (uint16_t)nlen; a->out_off = off; a->out_cap = (uint16_t)cap;
             a->weight = an_w + add_w;
         }
@@ -552,15 +557,15 @@ __device__ inline bool dgw_merge_out_group(DgGraph &g, int u, const DgNode &nu, 
         const unsigned long long km = __ballot(keep);
         if (keep) {
             const int idx = __popcll(km & DG_LT(lane));
-            g.pool[nu.out_off + 2 * idx] = (uint32_t)d;
+            DG_PW(g, nu.out_off + 2 * idx) = (uint32_t)d;
             if (lane == an_lane) cnt += add_cnt;
-            g.pool[nu.out_off + 2 * idx + 1] = (uint32_t)cnt;
+            DG_PW(g, nu.out_off + 2 * idx + 1) = (uint32_t)cnt;
         }
-        if (lane == 0) g.nd[u].out_len = (uint16_t)__popcll(km);
+        if (lane == 0) DG_NV(g, u).out_len = (uint16_t)__popcll(km);
     }
     // AlnGraphBoost.cpp:269-273 for every victim
     if ((vm >> lane) & 1ull) {
-        DgNode *vn = &g.nd[d];
+        DgNode *vn = &DG_NV(g, d);
         vn->out_len = 0; vn->in_len = 0; vn->flags |= DG_NF_DELETED;
     }
     return true;
@@ -579,9 +584,9 @@ __device__ inline bool dgw_merge_in_group(DgGraph &g, int n, const DgNode &nn, u
     const bool member = (M >> lane) & 1ull;
     const bool victim = (vm >> lane) & 1ull;
     uint4 h2 = make_uint4(0, 0, 0, 0);
-    if (member) h2 = dg_hi16(&g.nd[s]);
+    if (member) h2 = dg_hi16(&DG_NV(g, s));
     int c0 = 0;
-    if (member) c0 = (int)g.pool[DG_H2_OUTOFF(h2) + 1];     // count of its single out edge (-> n)
+    if (member) c0 = (int)DG_PW(g, DG_H2_OUTOFF(h2) + 1);     // count of its single out edge (-> n)
     // victims' in entries flattened onto lanes 0..L-1, victims in order
     int L = 0, e = 0;
     uint32_t src_off = 0;
@@ -599,9 +604,9 @@ __device__ inline bool dgw_merge_in_group(DgGraph &g, int n, const DgNode &nn, u
     if (L > 64) return false;
     const bool fl = lane < L;
     int n1 = -1;
-    if (fl) n1 = (int)g.pool[src_off + e];
+    if (fl) n1 = (int)DG_PW(g, src_off + e);
     uint4 hn1 = make_uint4(0, 0, 0, 0);
-    if (fl) hn1 = dg_lo16(&g.nd[n1]);
+    if (fl) hn1 = dg_lo16(&DG_NV(g, n1));
     if (__ballot(fl && DG_H_OUTLEN(hn1) > 64)) return false;
 
     // ---- nothing has been modified up to here ----
@@ -609,8 +614,8 @@ __device__ inline bool dgw_merge_in_group(DgGraph &g, int n, const DgNode &nn, u
     const int add_cnt = dg_wave_sum_masked(c0, vm);
     const int add_w = dg_wave_sum_masked(DG_H_WEIGHT(h), vm);
     if (lane == an_lane) {
-        g.pool[DG_H2_OUTOFF(h2) + 1] = (uint32_t)(c0 + add_cnt);
-        g.nd[an].weight = DG_H_WEIGHT(h) + add_w;
+        DG_PW(g, DG_H2_OUTOFF(h2) + 1) = (uint32_t)(c0 + add_cnt);
+        DG_NV(g, an).weight = DG_H_WEIGHT(h) + add_w;
     }
     // :193-212 re-point the victims' in edges to the survivor, in order
     uint32_t a_in_off = (uint32_t)DG_RL(DG_H2_INOFF(h2), an_lane);
@@ -623,11 +628,11 @@ __device__ inline bool dgw_merge_in_group(DgGraph &g, int n, const DgNode &nn, u
         const int x = DG_RL(n1, f);
         rem &= ~__ballot(fl && n1 == x);
         // out[x]: drop the entries that point at victims, fold their counts into x->an
-        const uint4 hx2 = dg_hi16(&g.nd[x]);
+        const uint4 hx2 = dg_hi16(&DG_NV(g, x));
         const int xlen = DG_RL(DG_H_OUTLEN(hn1), f);
         const uint32_t xoff = DG_H2_OUTOFF(hx2);
         int dst = -1, c = 0;
-        if (lane < xlen) { dst = (int)g.pool[xoff + 2 * lane]; c = (int)g.pool[xoff + 2 * lane + 1]; }
+        if (lane < xlen) { dst = (int)DG_PW(g, xoff + 2 * lane); c = (int)DG_PW(g, xoff + 2 * lane + 1); }
         bool isv = false;
         for (unsigned long long m = vm; m; m &= m - 1ull) isv |= (dst == DG_RL(s, __ffsll((long long)m) - 1));
         const unsigned long long vmask = __ballot(lane < xlen && isv);
@@ -638,12 +643,12 @@ __device__ inline bool dgw_merge_in_group(DgGraph &g, int n, const DgNode &nn, u
         int nlen = __popcll(km);
         if (keep) {
             const int idx = __popcll(km & DG_LT(lane));
-            g.pool[xoff + 2 * idx] = (uint32_t)dst;
-            g.pool[xoff + 2 * idx + 1] = (uint32_t)(((apos >> lane) & 1ull) ? c + csum : c);
+            DG_PW(g, xoff + 2 * idx) = (uint32_t)dst;
+            DG_PW(g, xoff + 2 * idx + 1) = (uint32_t)(((apos >> lane) & 1ull) ? c + csum : c);
         }
         if (!apos) {
             // new edge x->an: END of out[x] (room is there: at least one entry was dropped)
-            if (lane == 0) { g.pool[xoff + 2 * nlen] = (uint32_t)an; g.pool[xoff + 2 * nlen + 1] = (uint32_t)csum; }
+            if (lane == 0) { DG_PW(g, xoff + 2 * nlen) = (uint32_t)an; DG_PW(g, xoff + 2 * nlen + 1) = (uint32_t)csum; }
             nlen++;
             // ... and END of in[an]
             if (a_in_len + 1 > a_in_cap) {
@@ -651,29 +656,29 @@ __device__ inline bool dgw_merge_in_group(DgGraph &g, int n, const DgNode &nn, u
                 if (ncap < 4) ncap = 4;
                 const uint32_t noff = dg_wave_alloc(g, ncap, lane);
                 if (noff == 0xFFFFFFFFu) return true;
-                if (lane < a_in_len) g.pool[noff + lane] = g.pool[a_in_off + lane];
-                for (int i = 64 + lane; i < a_in_len; i += 64) g.pool[noff + i] = g.pool[a_in_off + i];
+                if (lane < a_in_len) DG_PW(g, noff + lane) = DG_PW(g, a_in_off + lane);
+                for (int i = 64 + lane; i < a_in_len; i += 64) DG_PW(g, noff + i) = DG_PW(g, a_in_off + i);
                 a_in_off = noff; a_in_cap = (int)ncap;
             }
-            if (lane == 0) g.pool[a_in_off + a_in_len] = (uint32_t)x;
+            if (lane == 0) DG_PW(g, a_in_off + a_in_len) = (uint32_t)x;
             a_in_len++;
             a_dirty = true;
         }
-        if (lane == 0) g.nd[x].out_len = (uint16_t)nlen;
+        if (lane == 0) DG_NV(g, x).out_len = (uint16_t)nlen;
     }
     if (a_dirty && lane == 0) {
-        DgNode *a = &g.nd[an];
+        DgNode *a = &DG_NV(g, an);
         a->in_len = (uint16_t)a_in_len; a->in_off = a_in_off; a->in_cap = (uint16_t)a_in_cap;
     }
     // in[n] without the victims (stable)
     {
         const bool keep = valid_in && !victim;
         const unsigned long long km = __ballot(keep);
-        if (keep) g.pool[nn.in_off + __popcll(km & DG_LT(lane))] = (uint32_t)s;
-        if (lane == 0) g.nd[n].in_len = (uint16_t)__popcll(km);
+        if (keep) DG_PW(g, nn.in_off + __popcll(km & DG_LT(lane))) = (uint32_t)s;
+        if (lane == 0) DG_NV(g, n).in_len = (uint16_t)__popcll(km);
     }
     if (victim) {
-        DgNode *vn = &g.nd[s];
+        DgNode *vn = &DG_NV(g, s);
         vn->out_len = 0; vn->in_len = 0; vn->flags |= DG_NF_DELETED;
     }
     return true;
@@ -815,7 +820,7 @@ __global__ __launch_bounds__(PF ? 128 : 64) __attribute__((amdgpu_waves_per_eu(8
             // gfx950 counts stores in vmcnt, so a load issued behind the previous visit's stores
             // waits for them to reach L2: the record was requested before those stores went out
             DgNode nu;
-            if (pre) nu = nu_next; else nu = g.nd[u];
+            if (pre) nu = nu_next; else nu = DG_NV(g, u);
             const int eff_in = skip_in ? 0 : (int)nu.in_len, eff_out = in_only ? 0 : (int)nu.out_len;
             if (eff_in <= 32 && eff_out <= 32) {
 #ifdef DG_STAMPS
@@ -827,13 +832,13 @@ __global__ __launch_bounds__(PF ? 128 : 64) __attribute__((amdgpu_waves_per_eu(8
                 // one address per lane, two independent loads (an in lane's second word is not used)
                 const uint32_t ea = is_in ? nu.in_off + (uint32_t)idx : nu.out_off + 2u * (uint32_t)idx;
                 int nbr = 0, cnt = 0;
-                if (valid) { nbr = (int)g.pool[ea]; cnt = (int)g.pool[ea + 1]; }
+                if (valid) { nbr = (int)DG_PW(g, ea); cnt = (int)DG_PW(g, ea + 1); }
 #ifdef DG_STAMPS
                 asm volatile("" ::"v"(nbr), "v"(cnt));
                 const unsigned long long tq2 = clock64();
 #endif
                 uint4 h = make_uint4(0, 0, 0, 0);
-                if (valid) h = dg_lo16(&g.nd[nbr]);
+                if (valid) h = dg_lo16(&DG_NV(g, nbr));
                 // in lanes: out_len == 1 (low half of h.x), out lanes: in_len == 1 (high half)
                 const unsigned long long cand = __ballot(((h.x >> (is_in ? 0u : 16u)) & 0xffffu) == 1u);
 #ifdef DG_STAMPS
@@ -867,7 +872,7 @@ __global__ __launch_bounds__(PF ? 128 : 64) __attribute__((amdgpu_waves_per_eu(8
                         last_out = b;
                         const int an_lane = __ffsll((long long)M) - 1;
                         if (((M >> lane) & 1ull) && lane != an_lane) live = false;     // victims are gone
-                        if (live) h = dg_lo16(&g.nd[nbr]);                             // pending / lens may have moved
+                        if (live) h = dg_lo16(&DG_NV(g, nbr));                             // pending / lens may have moved
                     }
                     if (!bail) {
                         if (!g.err) {
@@ -883,8 +888,8 @@ __global__ __launch_bounds__(PF ? 128 : 64) __attribute__((amdgpu_waves_per_eu(8
                             }
                             // (a vertex this visit releases still shows pending 1 in this copy; the
                             // visit of a vertex never reads its own pending counter)
-                            if (have_next) nu_next = g.nd[u_next];
-                            if (live) g.nd[nbr].pending = pend;
+                            if (have_next) nu_next = DG_NV(g, u_next);
+                            if (live) DG_NV(g, nbr).pending = pend;
                             if (live && pend == 0) {
                                 const uint32_t pos = qt + (uint32_t)__popcll(rm & DG_LT(lane));
                                 if (pos < N) { g.queue[pos] = nbr; s_ring[pos & (DG_QRING - 1)] = nbr; }
@@ -911,13 +916,13 @@ __global__ __launch_bounds__(PF ? 128 : 64) __attribute__((amdgpu_waves_per_eu(8
         int sp = skip_in ? 0 : 1;
         int fr_n = u, fr_last = -1;                       // top frame lives in registers
         while (sp > 0) {
-            const DgNode nn = g.nd[fr_n];
+            const DgNode nn = DG_NV(g, fr_n);
             if (nn.in_len > 32) { scalar = true; break; }
             const bool valid = lane < nn.in_len;
             int s = 0;
-            if (valid) s = (int)g.pool[nn.in_off + lane];
+            if (valid) s = (int)DG_PW(g, nn.in_off + lane);
             uint4 h = make_uint4(0, 0, 0, 0);
-            if (valid) h = dg_lo16(&g.nd[s]);
+            if (valid) h = dg_lo16(&DG_NV(g, s));
             const unsigned long long cand = __ballot(valid && DG_H_OUTLEN(h) == 1);
             unsigned long long M = 0;
             int b = 256;
@@ -963,14 +968,14 @@ __global__ __launch_bounds__(PF ? 128 : 64) __attribute__((amdgpu_waves_per_eu(8
         }
         int last_out = -1;
         while (!done && !g.err) {
-            const DgNode nu = g.nd[u];
+            const DgNode nu = DG_NV(g, u);
             const int out_len = nu.out_len;
             if (out_len > 64) break;                      // bookkeeping by the single-lane loop below
             const bool valid = lane < out_len;
             int d = 0, cnt = 0;
-            if (valid) { d = (int)g.pool[nu.out_off + 2 * lane]; cnt = (int)g.pool[nu.out_off + 2 * lane + 1]; }
+            if (valid) { d = (int)DG_PW(g, nu.out_off + 2 * lane); cnt = (int)DG_PW(g, nu.out_off + 2 * lane + 1); }
             uint4 h = make_uint4(0, 0, 0, 0);
-            if (valid) h = dg_lo16(&g.nd[d]);
+            if (valid) h = dg_lo16(&DG_NV(g, d));
             if (!scalar) {
                 const unsigned long long cand = __ballot(valid && DG_H_INLEN(h) == 1);
                 unsigned long long M = 0;
@@ -997,7 +1002,7 @@ __global__ __launch_bounds__(PF ? 128 : 64) __attribute__((amdgpu_waves_per_eu(8
             // AlnGraphBoost.cpp:143-158: mark out-edges visited, enqueue targets whose
             // in-edges are now all visited, in out-list order
             const int pend = DG_H_PEND(h) - 1;
-            if (valid) g.nd[d].pending = pend;
+            if (valid) DG_NV(g, d).pending = pend;
             const unsigned long long rm = __ballot(valid && pend == 0);
             if (valid && pend == 0) {
                 const uint32_t pos = qt + (uint32_t)__popcll(rm & DG_LT(lane));
