@@ -41,7 +41,9 @@ struct Ctx {
     uint64_t sum_len = 0, sum_bb = 0, mat_cells = 0, blob_bytes = 0;
     bool have_bb = false;
     std::vector<uint32_t> h_tlen, h_aln_len, h_aln_start, h_aln_tgt;
-    std::vector<uint64_t> h_aln_begin, h_aln_off, h_mat_base, h_bbv_base, h_bb_off;
+    std::vector<uint64_t> h_aln_begin, h_aln_off, h_mat_base, h_bbv_base, h_bb_off, h_matc_base;
+    std::vector<uint32_t> h_matc_stride;
+    uint64_t matc_cells = 0;
     std::vector<uint8_t> h_tactive;
     std::vector<uint32_t> h_ch_base, h_ch_aln;      // chunk tables of k_norm_*
     std::vector<uint32_t> h_ck_base;                // first k_emit checkpoint of each alignment
@@ -52,7 +54,7 @@ struct Ctx {
 
     // device buffers
     DevBuf d_q, d_t, d_aln_off, d_aln_len, d_aln_start, d_aln_tgt, d_tlen, d_aln_begin, d_tactive,
-        d_bb, d_bb_off, d_mat_base, d_bbv_base;
+        d_bb, d_bb_off, d_mat_base, d_bbv_base, d_matc_base, d_matc_stride;
     DevBuf d_nmis, d_norm_off, d_n_lo, d_n_hi, d_n_start, d_n_ins, d_n_del, d_norm;
     DevBuf d_ch_aln, d_ch_base, d_ch_k0, d_ch_next, d_ch_w, d_ch_tb, d_ch_flag, d_ch_src, d_ch_out, d_ch_adv,
         d_n_lb, d_norm_tmp, d_ckpt, d_ck_base;
@@ -163,6 +165,7 @@ void fill_params(Ctx *c, DgParams &p) {
     p.bb = c->have_bb ? (const uint8_t *)c->d_bb.p : nullptr;
     p.bb_off = (const uint64_t *)c->d_bb_off.p;
     p.mat_base = (const uint64_t *)c->d_mat_base.p;
+    p.matc_base = (const uint64_t *)c->d_matc_base.p; p.matc_stride = (const uint32_t *)c->d_matc_stride.p;
     p.bbv_base = (const uint64_t *)c->d_bbv_base.p;
     p.T = c->T; p.A = c->A;
     p.trim = c->opts.trim; p.min_len = c->opts.min_len;
@@ -228,7 +231,7 @@ int launch_all(Ctx *c) {
     HIPCHK(c, hipMemsetAsync(c->d_st.p, 0, sizeof(DgStatus), s));
     HIPCHK(c, hipMemsetAsync(c->d_cns_len.p, 0, (size_t)c->T * 4, s));
     HIPCHK(c, hipMemsetAsync(c->d_n_seg.p, 0, (size_t)c->T * 4, s));
-    if (c->mat_cells) HIPCHK(c, hipMemsetAsync(c->d_matC.p, 0, c->mat_cells * 4, s));
+    if (c->matc_cells) HIPCHK(c, hipMemsetAsync(c->d_matC.p, 0, c->matc_cells * 4, s));
     HIPCHK(c, hipEventRecord(c->ev[0], s));
     launch_normalize(c, p);
     HIPCHK(c, hipEventRecord(c->ev[1], s));
@@ -239,7 +242,7 @@ int launch_all(Ctx *c) {
     hipLaunchKernelGGL(k_carve, dim3(1), dim3(1024), 0, s, p);
     if (c->T > 0) {
         const uint32_t rows4 = (c->max_tlen + 2 + 4 * DG_LPW - 1) / (4 * DG_LPW);   // 4 waves x DG_LPW positions per block
-        hipLaunchKernelGGL(k_groups, dim3(c->T, rows4), dim3(256), 0, s, p);
+        hipLaunchKernelGGL(k_groups, dim3(c->T, (c->max_tlen + 2 + 31) / 32), dim3(256), 0, s, p);
         hipLaunchKernelGGL(k_gscan, dim3(c->T), dim3(1024), 0, s, p);
         hipLaunchKernelGGL(k_init_nodes, dim3(c->T, (c->max_tlen + 2 + 255) / 256), dim3(256), 0, s, p);
         if (c->A > 0)
@@ -322,7 +325,7 @@ void dagcon_destroy(dagcon_ctx *ctx) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     DevBuf *all[] = {&c->d_q, &c->d_t, &c->d_aln_off, &c->d_aln_len, &c->d_aln_start, &c->d_aln_tgt,
-                     &c->d_tlen, &c->d_aln_begin, &c->d_tactive, &c->d_bb, &c->d_bb_off, &c->d_mat_base,
+                     &c->d_tlen, &c->d_aln_begin, &c->d_tactive, &c->d_bb, &c->d_bb_off, &c->d_mat_base, &c->d_matc_base, &c->d_matc_stride,
                      &c->d_bbv_base, &c->d_nmis, &c->d_norm_off, &c->d_n_lo, &c->d_n_hi, &c->d_n_start, &c->d_ch_aln, &c->d_ch_base, &c->d_ch_k0, &c->d_ch_next, &c->d_ch_w, &c->d_ch_tb, &c->d_ch_flag, &c->d_ch_src, &c->d_ch_out, &c->d_ch_adv, &c->d_n_lb, &c->d_norm_tmp, &c->d_ckpt, &c->d_ck_base,
                      &c->d_n_ins, &c->d_n_del, &c->d_norm, &c->d_node_base, &c->d_n_nodes,
                      &c->d_pool_base, &c->d_pool_size, &c->d_pool_top, &c->d_t_nins, &c->d_matA, &c->d_matD,
@@ -358,6 +361,7 @@ int dagcon_upload(dagcon_ctx *ctx, const dagcon_batch *b) {
     c->h_aln_begin.assign(T + 1, 0);
     c->h_tactive.assign(T, 0);
     c->h_mat_base.assign(T, 0);
+    c->h_matc_base.assign(T, 0); c->h_matc_stride.assign(T, 0); c->matc_cells = 0;
     c->h_bbv_base.assign(T, 0);
     c->h_bb_off.assign(T, 0);
     c->h_aln_len.clear(); c->h_aln_start.clear(); c->h_aln_tgt.clear(); c->h_aln_off.clear();
@@ -397,6 +401,9 @@ int dagcon_upload(dagcon_ctx *ctx, const dagcon_batch *b) {
             return fail(c, DAGCON_ERR_UNSUPPORTED, "tlen of target %u exceeds %u", t, 4u * 65535u - 2u);
         c->h_mat_base[t] = c->mat_cells;
         c->mat_cells += ((uint64_t)b->tlen[t] + 2) * k;
+        c->h_matc_stride[t] = (b->tlen[t] + 2 + 7) & ~7u;      // matC is [read][position], rows 32-byte aligned
+        c->h_matc_base[t] = c->matc_cells;
+        c->matc_cells += (uint64_t)c->h_matc_stride[t] * k;
         c->h_bbv_base[t] = c->sum_bb;                      // multiple of 4: 16-byte loads of bid[]
         c->sum_bb += ((uint64_t)b->tlen[t] + 2 + 3) & ~3ull;
         if (c->have_bb) {
@@ -453,6 +460,8 @@ int dagcon_upload(dagcon_ctx *ctx, const dagcon_batch *b) {
     if ((r = upload_vec(c, c->d_tactive, c->h_tactive))) return r;
     if ((r = upload_vec(c, c->d_bb_off, c->h_bb_off))) return r;
     if ((r = upload_vec(c, c->d_mat_base, c->h_mat_base))) return r;
+    if ((r = upload_vec(c, c->d_matc_base, c->h_matc_base))) return r;
+    if ((r = upload_vec(c, c->d_matc_stride, c->h_matc_stride))) return r;
     if ((r = upload_vec(c, c->d_bbv_base, c->h_bbv_base))) return r;
     if ((r = upload_vec(c, c->d_ch_base, c->h_ch_base))) return r;
     if ((r = upload_vec(c, c->d_ch_aln, c->h_ch_aln))) return r;
@@ -474,7 +483,7 @@ int dagcon_upload(dagcon_ctx *ctx, const dagcon_batch *b) {
     ENSURE(c, c->d_pool_base, (size_t)T * 8); ENSURE(c, c->d_pool_size, T4); ENSURE(c, c->d_pool_top, T4);
     ENSURE(c, c->d_t_nins, T4);
     ENSURE(c, c->d_matA, c->mat_cells * 4); ENSURE(c, c->d_matD, c->mat_cells * 4);
-    ENSURE(c, c->d_matC, c->mat_cells * 4);
+    ENSURE(c, c->d_matC, c->matc_cells * 4 + 256);
     ENSURE(c, c->d_cov, c->sum_bb * 4); ENSURE(c, c->d_gcount, c->sum_bb * 4);
     ENSURE(c, c->d_gbase, c->sum_bb * 4); ENSURE(c, c->d_bid, c->sum_bb * 4);
     ENSURE(c, c->d_cns_off, (size_t)T * 8); ENSURE(c, c->d_cns_len, T4);

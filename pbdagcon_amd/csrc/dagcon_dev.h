@@ -131,7 +131,10 @@ struct DgParams {
     int32_t *cov;                  // coverage (AlnGraphBoost.cpp:76,87)
     // ---- matrices [position][read] ----
     uint32_t *matA, *matD;         // arrival / departure
-    uint32_t *matC;                // insertion run length, then exclusive prefix over reads
+    uint32_t *matC;                // [read][position] (row stride matc_stride): insertion run length in front of
+                                   // the position, then its exclusive prefix over reads
+    const uint64_t *matc_base;     // [T] offset of the target's K rows
+    const uint32_t *matc_stride;   // [T] (tlen + 2) rounded up to a multiple of 4 cells
     // ---- vertex arena ----
     DgNode *nodes;
     int32_t *best, *queue;

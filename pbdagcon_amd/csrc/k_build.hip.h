@@ -110,7 +110,7 @@ __device__ inline void dg_finish_alignment(const DgParams &p, uint32_t a, uint16
             const uint64_t ab = p.aln_begin[t_idx];
             r = (uint32_t)(a - ab);
             K = (uint32_t)(p.aln_begin[t_idx + 1] - ab);
-            Cm = p.matC + p.mat_base[t_idx];
+            Cm = p.matC + p.matc_base[t_idx] + (uint64_t)r * p.matc_stride[t_idx];   // the read's row
         }
     }
     const uint32_t tlen = graph ? p.tlen[t_idx] : 0xFFFFFFFFu;
@@ -124,7 +124,7 @@ __device__ inline void dg_finish_alignment(const DgParams &p, uint32_t a, uint16
         if (qb_ == tb_ || qb_ == DG_GAP) {                                                \
             if (Cm && conf && ((start + adv) & ((1u << p.emit_shift) - 1u)) == 0 && start + adv <= tlen + 1) \
                 ck[(start + adv) >> p.emit_shift] = ci_ - run;                            \
-            if (run) { if (Cm && conf && start + adv <= tlen + 1) Cm[(uint64_t)(start + adv) * K + r] = run; run = 0; } \
+            if (run) { if (Cm && conf && start + adv <= tlen + 1) Cm[start + adv] = run; run = 0; } \
             adv++; n_del += (qb_ != tb_);                                                 \
             if ((uint64_t)start - 1 + adv > (uint64_t)tlen) conf = false;                 \
         } else if (tb_ == DG_GAP) { n_ins++; run++; }                                     \
@@ -145,7 +145,7 @@ __device__ inline void dg_finish_alignment(const DgParams &p, uint32_t a, uint16
     while (i < hi) { const uint16_t c = buf[i]; DG_FIN_COL(c, i); i++; }
     if (run && Cm && conf && ((start + adv) & ((1u << p.emit_shift) - 1u)) == 0 && start + adv <= tlen + 1)
         ck[(start + adv) >> p.emit_shift] = hi - run;     // a trailing insertion run: the position after the read's last
-    if (run && Cm && conf && start + adv <= tlen + 1) Cm[(uint64_t)(start + adv) * K + r] = run;
+    if (run && Cm && conf && start + adv <= tlen + 1) Cm[start + adv] = run;
 #undef DG_FIN_COL
     p.n_lo[a] = lo; p.n_hi[a] = hi; p.n_start[a] = start;
     p.n_ins[a] = n_ins; p.n_del[a] = n_del;
@@ -445,7 +445,7 @@ __global__ __launch_bounds__(64) void k_norm_finish(DgParams p) {
             const uint64_t ab = p.aln_begin[t_idx];
             r = (uint32_t)(a - ab);
             K = (uint32_t)(p.aln_begin[t_idx + 1] - ab);
-            Cm = p.matC + p.mat_base[t_idx];
+            Cm = p.matC + p.matc_base[t_idx] + (uint64_t)r * p.matc_stride[t_idx];   // the read's row
         }
     }
     const uint32_t tlen = graph ? p.tlen[t_idx] : 0xFFFFFFFFu;
@@ -486,7 +486,7 @@ __global__ __launch_bounds__(64) void k_norm_finish(DgParams p) {
                 // it may end in the insertion run that belongs to this position)
                 if (Cm && conf && ((start + adv) & ck_mask) == 0 && start + adv <= tlen + 1 && !(8u * v + (uint32_t)k == 0 && o > lo))
                     ck[(start + adv) >> p.emit_shift] = o + 8u * v + (uint32_t)k - run;
-                if (run) { if (Cm && conf && start + adv <= tlen + 1) Cm[(uint64_t)(start + adv) * K + r] = run; run = 0; }
+                if (run) { if (Cm && conf && start + adv <= tlen + 1) Cm[start + adv] = run; run = 0; }
                 adv++; n_del += (qb != tb);
                 if ((uint64_t)start - 1 + adv > (uint64_t)tlen) conf = false;
             } else if (tb == DG_GAP) { n_ins++; run++; }
@@ -498,7 +498,7 @@ __global__ __launch_bounds__(64) void k_norm_finish(DgParams p) {
     // a trailing insertion run of the read belongs to the position after its last one
     if (any && Cm && conf && ((start + adv) & ck_mask) == 0 && start + adv <= tlen + 1 && (o + f1 < hi || run))
         ck[(start + adv) >> p.emit_shift] = o + f1 - run;
-    if (run && Cm && conf && start + adv <= tlen + 1) Cm[(uint64_t)(start + adv) * K + r] = run;
+    if (run && Cm && conf && start + adv <= tlen + 1) Cm[start + adv] = run;
     if (n_ins) atomicAdd(&p.n_ins[a], n_ins);
     if (n_del) atomicAdd(&p.n_del[a], n_del);
     if (graph && any && !conf) {
@@ -646,7 +646,7 @@ __global__ __launch_bounds__(1024) void k_carve(DgParams p) {
 }
 
 // ---------------------------------------------------------------------------
-// k_groups: one wave per backbone position.  matC row -> exclusive prefix over
+// k_groups: one wave per 8 backbone positions.  matC column -> exclusive prefix over
 // reads (in place); gcount[p] = inserted vertices whose _bbMap is p.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_groups(DgParams p) {
@@ -655,26 +655,41 @@ __global__ __launch_bounds__(256) void k_groups(DgParams p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t blen = p.tlen[t];
     const uint32_t K = (uint32_t)(p.aln_begin[t + 1] - p.aln_begin[t]);
-    uint32_t *row0 = p.matC + p.mat_base[t];
+    uint32_t *col0 = p.matC + p.matc_base[t];
+    const uint32_t cstride = p.matc_stride[t];              // a multiple of 8: rows start 32-byte aligned
     uint32_t *gcount = p.gcount + p.bbv_base[t];
-    for (uint32_t pi = 0; pi < DG_LPW; pi++) {
-    const uint32_t pos = (blockIdx.y * 4 + wave) * DG_LPW + pi;
-    if (pos >= blen + 2) return;
-    uint32_t *row = row0 + (uint64_t)pos * K;
-    uint32_t carry = 0;
+    // a wave takes 8 consecutive positions: a lane (= a read) loads and stores them as two 16-byte
+    // pieces of its row
+    const uint32_t pos0 = (blockIdx.y * 4 + wave) * 8u;
+    if (pos0 >= blen + 2) return;
+    uint32_t carry[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) carry[j] = 0;
     for (uint32_t r0 = 0; r0 < K; r0 += DG_WAVE) {
         const uint32_t r = r0 + lane;
-        const uint32_t v = r < K ? row[r] : 0u;
-        uint32_t incl = v;
-        for (int o = 1; o < DG_WAVE; o <<= 1) {
-            const uint32_t up = __shfl_up(incl, o);
-            if (lane >= o) incl += up;
+        uint4 *cell = reinterpret_cast<uint4 *>(col0 + (uint64_t)r * cstride + pos0);
+        uint4 a = make_uint4(0, 0, 0, 0), b = a;
+        if (r < K) { a = cell[0]; b = cell[1]; }
+        uint32_t v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        uint32_t ex[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            uint32_t incl = v[j];
+            for (int o = 1; o < DG_WAVE; o <<= 1) {
+                const uint32_t up = __shfl_up(incl, o);
+                if (lane >= o) incl += up;
+            }
+            ex[j] = carry[j] + incl - v[j];
+            carry[j] += __shfl(incl, DG_WAVE - 1);
         }
-        if (r < K) row[r] = carry + incl - v;
-        carry += __shfl(incl, DG_WAVE - 1);
+        if (r < K) {
+            cell[0] = make_uint4(ex[0], ex[1], ex[2], ex[3]);
+            cell[1] = make_uint4(ex[4], ex[5], ex[6], ex[7]);
+        }
     }
-    if (lane == 0) gcount[pos] = carry;
-    }
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+        if (lane == j && pos0 + j < blen + 2) gcount[pos0 + j] = carry[j];
 }
 
 // ---------------------------------------------------------------------------
@@ -787,7 +802,7 @@ __global__ __launch_bounds__(64) void k_emit(DgParams p) {
     const uint32_t *bid = p.bid + bv, *gbase = p.gbase + bv;
     uint32_t *Am = p.matA + p.mat_base[t];
     uint32_t *Dm = p.matD + p.mat_base[t];
-    const uint32_t *Cm = p.matC + p.mat_base[t];
+    const uint32_t *Cm = p.matC + p.matc_base[t] + (uint64_t)(done ? 0 : r) * p.matc_stride[t];   // the read's row
     uint32_t *pool = p.pool + p.pool_base[t];
     DgNode *ndt = p.nodes + nb;
     // pool words / vertex records / matrix cells: uniform base + 32-bit byte offset (see k_merge)
@@ -818,10 +833,8 @@ __global__ __launch_bounds__(64) void k_emit(DgParams p) {
                     if (qb == DG_GAP) { d++; continue; }
                     if (tb == DG_GAP) {                     // last vertex of the insertion run of position P0 - d
                         prev_pos = P0 - d;
-                        const uint32_t c0 = Cm[(uint64_t)prev_pos * K + r];
-                        const uint32_t c1 = r + 1 < K ? Cm[(uint64_t)prev_pos * K + r + 1] : p.gcount[bv + prev_pos];
+                        const uint32_t c1 = r + 1 < K ? Cm[p.matc_stride[t] + prev_pos] : p.gcount[bv + prev_pos];
                         prev = gbase[prev_pos] + c1 - 1u;
-                        (void)c0;
                         prev_bb = false;
                         break;
                     }
@@ -888,9 +901,14 @@ __global__ __launch_bounds__(64) void k_emit(DgParams p) {
                 const uint4 v = gp[k];
                 gbv[4 * k] = v.x; gbv[4 * k + 1] = v.y; gbv[4 * k + 2] = v.z; gbv[4 * k + 3] = v.w;
             }
+            // (the row is padded to a multiple of 8 cells and pos0 is a multiple of 4: whole
+            // 16-byte pieces; what lies past the exit position is not used)
+            const uint4 *cp = reinterpret_cast<const uint4 *>(Cm + pos0);
 #pragma unroll
-            for (int j = 0; j < DG_EB; j++)
-                cmv[j] = (!done && pos0 + j <= exitpos) ? DG_ECELL(const_cast<uint32_t *>(Cm), pos0 + j) : 0u;
+            for (int k = 0; k < DG_EB / 4; k++) {
+                const uint4 v = cp[k];
+                cmv[4 * k] = v.x; cmv[4 * k + 1] = v.y; cmv[4 * k + 2] = v.z; cmv[4 * k + 3] = v.w;
+            }
         }
         if (!done && i < hi && (i - c_base) + 24u > DG_ECOLS) DG_STAGE(i);
         uint32_t acell[DG_EB];
@@ -976,7 +994,7 @@ __global__ __launch_bounds__(64) void k_emit(DgParams p) {
             const uint8_t qb = DG_Q(c), tb = DG_T(c);
             if (qb == tb) { nxt = bid[q]; found = true; break; }
             if (qb == DG_GAP) { q++; i++; continue; }
-            if (tb == DG_GAP) { nxt = gbase[q] + Cm[(uint64_t)q * K + r]; found = true; break; }
+            if (tb == DG_GAP) { nxt = gbase[q] + Cm[q]; found = true; break; }
             i++;
         }
         if (!found) {                                     // nothing but deletions to the end (:106)
