@@ -470,8 +470,17 @@ __global__ __launch_bounds__(64) void k_norm_finish(DgParams p) {
     uint4 *dst4 = reinterpret_cast<uint4 *>(dst + h);
     const uint32_t nvec = (w + 7u) / 8u;
     uint4 prev = make_uint4(0, 0, 0, 0);
+    // a whole 128-byte line of the chunk (8 vectors) is requested at once: taking it 16 bytes at
+    // a time, with every lane on a line of its own, each line came in from L2 eight times
+    uint4 lin[8];
     for (uint32_t v = 0; v < nvec; v++) {
-        const uint4 cur = src4[v];
+        if ((v & 7u) == 0) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) lin[k] = v + k < nvec ? src4[v + k] : make_uint4(0, 0, 0, 0);
+        }
+        uint4 cur = lin[0];
+#pragma unroll
+        for (int k = 1; k < 8; k++) if ((v & 7u) == (uint32_t)k) cur = lin[k];
         if (v >= 1 && v - 1 < nb) dst4[v - 1] = dg_funnel_cols(prev, cur, h);
         prev = cur;
         if (8u * v + 8u <= f0 || 8u * v >= f1) continue;         // nothing of the window in this vector
