@@ -1,7 +1,7 @@
 // dagcon_api.hip -- host side of the C ABI (include/dagcon.h).
 //
 // Owns the HIP stream, the HBM arenas and the launch sequence of the hot path
-//   a1 k_count, k_norm_*    | a2 k_carve, k_init_nodes, k_emit, k_lists |
+//   a1 k_count, k_norm_*    | a2 k_carve, k_groups, k_emit, k_lists |
 //   b  k_merge              | c  k_bestpath
 // There is no CPU fallback anywhere in this file: without a HIP device
 // dagcon_create fails with DAGCON_ERR_NO_DEVICE.
@@ -244,7 +244,6 @@ int launch_all(Ctx *c) {
         const uint32_t rows4 = (c->max_tlen + 2 + 4 * DG_LPW - 1) / (4 * DG_LPW);   // 4 waves x DG_LPW positions per block
         hipLaunchKernelGGL(k_groups, dim3(c->T, (c->max_tlen + 2 + 31) / 32), dim3(256), 0, s, p);
         hipLaunchKernelGGL(k_gscan, dim3(c->T), dim3(1024), 0, s, p);
-        hipLaunchKernelGGL(k_init_nodes, dim3(c->T, (c->max_tlen + 2 + 255) / 256), dim3(256), 0, s, p);
         if (c->A > 0)
             hipLaunchKernelGGL(k_emit, dim3(c->T, (c->max_k + DG_ERPW - 1) / DG_ERPW, ((c->max_tlen + 2) >> c->emit_shift) + 1),
                                dim3(64), 0, s, p);

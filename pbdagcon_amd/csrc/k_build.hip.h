@@ -7,10 +7,9 @@
 //   k_carve      a2  exact vertex / pool needs per target, exclusive scans -> arena offsets
 //   k_groups     a2  per backbone position: exclusive scan of insertion run lengths over reads
 //   k_gscan      a2  per target: exclusive scan over positions -> position-ordered vertex ids
-//   k_init_nodes a2  backbone vertices (AlnGraphBoost.cpp:16-62)
 //   k_emit       a2  addAln (AlnGraphBoost.cpp:64-107): one lane per alignment walks its columns;
 //                    plain stores only (arrival / departure cells, inserted vertex records)
-//   k_lists      a2  addEdge dedupe (AlnGraphBoost.cpp:109-127) + coverage / weight / base:
+//   k_lists      a2  backbone vertices (AlnGraphBoost.cpp:16-62), addEdge dedupe (:109-127) + coverage / weight / base:
 //                    one wave per backbone position turns its arrival / departure row into
 //                    ordered adjacency lists (ballot / popcount peeling)
 #pragma once
@@ -737,31 +736,6 @@ __global__ __launch_bounds__(1024) void k_gscan(DgParams p) {
 }
 
 // ---------------------------------------------------------------------------
-// k_init_nodes: grid (T, chunks of 256 backbone positions).
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_init_nodes(DgParams p) {
-    const uint32_t t = blockIdx.x;
-    if (dg_failed(p) || !p.tactive[t]) return;
-    const uint32_t blen = p.tlen[t];
-    const uint32_t pos = blockIdx.y * 256 + threadIdx.x;
-    if (pos >= blen + 2) return;
-    const uint64_t bv = p.bbv_base[t] + pos;
-    const uint32_t v = p.bid[bv];
-    DgNode nd;
-    nd.out_len = 0; nd.in_len = 0; nd.flags = DG_NF_BACKBONE; nd.pad = 0;
-    if (pos == 0) nd.base = '^';
-    else if (pos == blen + 1) nd.base = '$';
-    else nd.base = p.bb ? p.bb[p.bb_off[t] + (pos - 1)] : (uint8_t)'N';
-    const bool inner = (pos >= 1 && pos <= blen);
-    nd.weight = inner ? 1 : 0;
-    nd.pending = 0;
-    nd.out_off = 0; nd.in_off = 0; nd.out_cap = 0; nd.in_cap = 0;
-    nd.bbpos = inner ? (int32_t)pos : 0;    // _bbMap: absent key (enter, exit) reads as 0
-    p.nodes[p.node_base[t] + v] = nd;
-    p.cov[bv] = 0;
-}
-
-// ---------------------------------------------------------------------------
 // k_emit: addAln.  One wave per (target, group of 64 reads, stretch of 1 << emit_shift
 // backbone positions), one lane per read.
 //
@@ -1155,17 +1129,22 @@ __global__ __launch_bounds__(256) void k_lists(DgParams p) {
         if (dir == 0) out_len = (uint32_t)n; else in_len = (uint32_t)n;
     }
     if (lane == 0) {
-        DgNode nd = p.nodes[nb + v];
+        // the whole record of the backbone vertex (AlnGraphBoost.cpp:16-62 + what addAln made of it)
+        const bool inner = pos >= 1 && pos <= blen;
+        DgNode nd;
         nd.out_len = (uint16_t)out_len;
         nd.in_len = (uint16_t)in_len;
+        nd.flags = DG_NF_BACKBONE; nd.pad = 0;
+        if (pos == 0) nd.base = '^';
+        else if (pos == blen + 1) nd.base = '$';
+        else if (n_cov) nd.base = (uint8_t)last_base;           // last read to cover the position (:79,:90)
+        else nd.base = p.bb ? p.bb[p.bb_off[t] + (pos - 1)] : (uint8_t)'N';
+        nd.weight = inner ? 1 + (int32_t)n_match : 0;           // :81
+        nd.pending = (int32_t)in_len;
         nd.out_off = out_off; nd.in_off = in_off;
         nd.out_cap = (uint16_t)out_cap; nd.in_cap = (uint16_t)in_cap;
-        nd.pending = (int32_t)in_len;
-        if (pos >= 1 && pos <= blen) {
-            nd.weight = 1 + (int32_t)n_match;                   // AlnGraphBoost.cpp:81
-            if (n_cov) nd.base = (uint8_t)last_base;            // last read to cover the position (:79,:90)
-            p.cov[bv + pos] = (int32_t)n_cov;                   // :76,:87
-        }
+        nd.bbpos = inner ? (int32_t)pos : 0;                    // _bbMap: absent key (enter, exit) reads as 0
+        p.cov[bv + pos] = inner ? (int32_t)n_cov : 0;           // :76,:87
         p.nodes[nb + v] = nd;
     }
     }
