@@ -1050,8 +1050,62 @@ __global__ __launch_bounds__(256) void k_lists(DgParams p) {
         if (dir == 0 && pos == blen + 1) continue;
         if (dir == 1 && pos == 0) continue;
         const uint32_t *row = dir == 0 ? Dm : Am;
-        // the list under construction: entry i on lane i while it fits a wave (K <= 62 always
-        // does), spilled to LDS beyond that
+        if (K <= DG_WAVE) {
+            // ---- one read per lane.  Entry 0 is the constructor's neighbour; a neighbour that is an
+            // inserted vertex of the adjacent group belongs to one read only, so it is an entry of
+            // its own with no comparing; only the other backbone vertices (deletion jumps, the exit,
+            // the enter) are grouped by peeling.  Entries go straight to the pool in the order of
+            // their first read. ----
+            const uint32_t cell = (uint32_t)lane < K ? row[lane] : 0u;
+            int32_t val = (int32_t)cell;                       // neighbour id + 1, 0 = none
+            if (dir == 1) {
+                const uint32_t idf = DG_CELL_ID(cell);
+                const unsigned long long covered = __ballot(cell != 0u);
+                if (pos <= blen) {
+                    n_cov += (uint32_t)__popcll(covered);
+                    n_match += (uint32_t)__popcll(__ballot(cell != 0u && idf != DG_CELL_DEL));
+                    if (covered) last_base = DG_CELL_BASE((uint32_t)__builtin_amdgcn_readlane((int)cell, 63 - __clzll((long long)covered)));
+                }
+                val = (cell != 0u && idf != DG_CELL_DEL) ? (int32_t)idf : 0;
+            }
+            const uint32_t gp = dir == 0 ? pos + 1 : pos;
+            const int32_t chain = (int32_t)p.bid[bv + (dir == 0 ? pos + 1 : pos - 1)] + 1;
+            const int32_t ulo = (int32_t)p.gbase[bv + gp] + 1, uhi = (int32_t)p.bid[bv + gp] + 1;
+            const unsigned long long cm = __ballot(val == chain);
+            const bool uniq = val >= ulo && val < uhi;
+            unsigned long long firsts = __ballot(uniq);
+            int32_t cnt = 1;
+            unsigned long long rem = __ballot(val != 0 && !uniq) & ~cm;
+            while (rem) {
+                const int first = __ffsll((long long)rem) - 1;
+                const int32_t x = __builtin_amdgcn_readlane(val, first);
+                const unsigned long long same = __ballot(val == x);
+                rem &= ~same;
+                if (lane == first) cnt = __popcll(same);
+                firsts |= 1ull << first;
+            }
+            const uint32_t n = 1u + (uint32_t)__popcll(firsts);
+            uint32_t off = dir == 0 ? out_off : in_off;
+            if (n > capb) {                                     // rare: move to the growth region
+                const uint32_t cap = n + 2u;
+                off = dg_pool_alloc(p, t, dir == 0 ? 2u * cap : cap, lane);
+                if (off == 0xFFFFFFFFu) return;
+                if (dir == 0) { out_off = off; out_cap = cap; } else { in_off = off; in_cap = cap; }
+            }
+            const uint32_t idx = 1u + (uint32_t)__popcll(firsts & ((1ull << lane) - 1ull));
+            if (dir == 0) {
+                if (lane == 0) { pool[off] = (uint32_t)(chain - 1); pool[off + 1] = (uint32_t)__popcll(cm); }
+                if ((firsts >> lane) & 1ull) { pool[off + 2 * idx] = (uint32_t)(val - 1); pool[off + 2 * idx + 1] = (uint32_t)cnt; }
+                out_len = n;
+            } else {
+                if (lane == 0) pool[off] = (uint32_t)(chain - 1);
+                if ((firsts >> lane) & 1ull) pool[off + idx] = (uint32_t)(val - 1);
+                in_len = n;
+            }
+            continue;
+        }
+        // ---- more than a wave of reads: the list under construction has entry i on lane i while it
+        // fits a wave, spilled to LDS beyond that ----
         int n = 1;
         int32_t lv = dir == 0 ? (int32_t)p.bid[bv + pos + 1] : (int32_t)p.bid[bv + pos - 1];
         int32_t lc = 0;
