@@ -6,7 +6,8 @@
 One "step" = one pass of the hot path (normalise -> build -> merge -> best path)
 over one batch of synthetic targets that is already resident in HBM, results
 brought back to the host (and, for N > 1, the FASTA payload gathered on rank 0
-over RCCL).  Workload at every N: BASELINE.json configs[1] per GPU -- 1,000
+over RCCL); the host-side conversion / gather of one step overlaps the device work of
+the next, all K steps complete inside the timed region.  Workload at every N: BASELINE.json configs[1] per GPU -- 1,000
 targets x 10 kb backbone x 40x coverage, sub/ins/del = 1 %/10 %/4 %, pbdagcon
 defaults -c 6 -m 500 -t 50 -- so scaling is weak (targets are independent; each
 rank owns a contiguous shard of the target index space and no collective is on
@@ -116,19 +117,25 @@ def main():
     def gather(res):
         return gather_fasta(fasta_bytes(batch, res), dist, torch, local_rank) if dist is not None else None
 
-    def step(prev):
-        """One pass of the hot path over the batch, results on the host.  The FASTA gather of the
-        previous step's results (host formatting + RCCL) runs while this step's kernels are on
-        the device; the last step's gather is done before the closing fence."""
-        ctx.run()
-        g = gather(prev) if prev is not None else None
-        return ctx.fetch(), g
+    def run_steps(n, collect=None):
+        """n passes of the hot path over the batch, each with its results brought to the host
+        (dagcon_run + dagcon_fetch).  While pass i+1 is on the device the host turns pass i's
+        results into records and (N > 1) gathers their FASTA over RCCL; the last pass's records and
+        gather are done before this returns."""
+        res = gathered = None
+        if n:
+            ctx.run()
+        for i in range(n):
+            raw = ctx.fetch_raw()
+            if collect is not None:
+                collect(ctx.timings())
+            if i + 1 < n:
+                ctx.run()
+            res = ctx.results_to_py(raw)
+            gathered = gather(res)
+        return res, gathered
 
-    res = None
-    for _ in range(args.warmup):
-        res, _ = step(res)
-    if res is not None:
-        gather(res)
+    run_steps(args.warmup)
 
     def fence():
         if dist is not None:
@@ -138,13 +145,11 @@ def main():
     merge_ms, total_ms = [], []
     fence()
     t0 = time.perf_counter()
-    res = None
-    for _ in range(args.steps):
-        res, _ = step(res)
-        tm = ctx.timings()
+    def collect(tm):
         merge_ms.append(tm["ms_merge"])
         total_ms.append(tm["ms_total"])
-    gathered = gather(res)
+
+    res, gathered = run_steps(args.steps, collect)
     fence()
     dt = time.perf_counter() - t0
     if dist is not None:

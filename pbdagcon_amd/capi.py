@@ -233,6 +233,16 @@ class Context:
         self._chk(self.L.dagcon_fetch(self.h, C.byref(r)))
         return _results_to_py(r)
 
+    def fetch_raw(self):
+        """dagcon_fetch without the conversion to Python objects: the returned struct points into
+        host memory the context owns until its next fetch (dagcon_run does not touch it), so a
+        caller can start the next run first and convert (results_to_py) meanwhile."""
+        r = Results()
+        self._chk(self.L.dagcon_fetch(self.h, C.byref(r)))
+        return r
+
+    results_to_py = staticmethod(lambda r: _results_to_py(r))
+
     def consensus(self, batch: HostBatch):
         """Per target: [(range0, range1, seq_bytes)]."""
         self._keep = batch
