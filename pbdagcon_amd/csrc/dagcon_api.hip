@@ -65,7 +65,7 @@ struct Ctx {
     DevBuf d_cns, d_cns_off, d_cns_len, d_seg_first, d_n_seg, d_seg_r0, d_seg_r1, d_st;
 
     uint64_t norm_cap = 0, node_cap = 0, pool_cap = 0, cns_cap = 0, seg_cap = 0;
-    uint32_t stk_words = 16384, growth_pct = 100, seg_max = 8, seg_env = 0;
+    uint32_t stk_words = 4096, growth_pct = 100, seg_max = 8, seg_env = 0;    // (scratch per target and segment: grown x4 and re-run on DG_E_STACK)
     uint64_t expected_workers = 0;                  // merge workers the batch will probably run (prefetch on / off)
 
     DgStatus h_st;
