@@ -473,6 +473,34 @@ def test_cli_end_to_end(tmp_path):
     assert out3.returncode == 0 and out3.stdout == out.stdout
 
 
+def test_full_size_configs1_properties(gpu_ctx_factory):
+    """BASELINE configs[1] at full size (1,000 targets x 10 kb x 40x, what bench.py times), through
+    properties that do not need the oracle on all of it: a second run of the same context gives
+    the same records; the records do not depend on how many pieces a target is swept in (8 per
+    target vs one sequential sweep); every target yields one record spanning the trimmed
+    backbone; a sample of targets equals the oracle's output."""
+    import hashlib
+    batch = synth.make_batch(1000, 10000, 40, seed=1000)
+    ctx = gpu_ctx_factory(min_cov=6, min_len=500, trim=50)
+    ctx.upload(batch)
+    ctx.run(); r1 = ctx.fetch()
+    ctx.run(); r2 = ctx.fetch()
+    assert r1 == r2
+    assert ctx.timings()["merge_segments"] == 8000
+    seq = gpu_ctx_factory(min_cov=6, min_len=500, trim=50, max_segments=1)
+    r3 = seq.consensus(batch)
+    assert seq.timings()["merge_segments"] == 1000
+    assert hashlib.sha256(repr(r3).encode()).digest() == hashlib.sha256(repr(r1).encode()).digest()
+    for t, segs in enumerate(r1):
+        assert len(segs) == 1, f"target {t}"
+        r0, r1_, s = segs[0]
+        assert r0 == 0 and r1_ == len(s) and 9700 <= len(s) <= 10100, f"target {t}: {r0} {r1_} {len(s)}"
+        assert set(s) <= set(b"ACGT")
+    sample = list(range(0, 1000, 97))
+    sub = batch.select(sample)
+    assert oracle_batch(sub, 6, 500, 50) == [r1[t] for t in sample]
+
+
 def test_config3_and_config5_shapes(gpu_ctx_factory):
     """BASELINE configs[2] / configs[4] shapes from the aligned strings inward: 50 kb x 60x
     (long target, more than 64... no: 60 reads, deep pools) and 20 kb x 30x with mixed target
