@@ -172,7 +172,9 @@ __device__ inline void dg_finish_alignment(const DgParams &p, uint32_t a, uint16
 //   k_norm_finish  lane per chunk: columns to their final place; what dg_finish_alignment
 //                  does, on the chunk's share of the trimmed window
 // ---------------------------------------------------------------------------
-#define DG_NCH 1024u           // input columns per window
+#ifndef DG_NCH
+#define DG_NCH 512u            // input columns per window (1024: +1.4 ms at configs[1], 256: the same, 128: +1.3 ms)
+#endif
 #define DG_CH_NONE 0xFFFFFFFFu
 
 __device__ __forceinline__ bool dg_match_col(uint8_t qb, uint8_t tb) { return qb == tb && qb != DG_GAP && qb != '.'; }

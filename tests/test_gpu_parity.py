@@ -388,7 +388,7 @@ def test_long_gap_runs_take_the_redo_path(gpu_ctx_factory):
 
 
 def test_chunked_normalize_boundaries(gpu_ctx_factory, monkeypatch):
-    """normalizeGaps runs in chunks of ~1024 input columns that start cold (k_norm_chunk).
+    """normalizeGaps runs in chunks of ~512 input columns that start cold (k_norm_chunk).
     Gaps in flight across chunk starts: an insertion in front of a long dinucleotide repeat
     slides through every chunk start inside it (the chunk in front is run again with the next
     one taken in), small alphabets keep many gaps moving, and trimAln's window ends inside,
