@@ -757,7 +757,9 @@ __global__ __launch_bounds__(1024) void k_gscan(DgParams p) {
 // position.  Columns come 8 at a time (16-byte loads) into two 64-bit registers,
 // the backbone ids of the batch in four 16-byte loads.
 // ---------------------------------------------------------------------------
+#ifndef DG_EB
 #define DG_EB 16
+#endif
 #ifndef DG_ERPW
 #define DG_ERPW 64          // reads per wave (16 or 32 were tried: no faster)
 #endif
