@@ -261,7 +261,6 @@ int launch_all(Ctx *c) {
     HIPCHK(c, hipEventRecord(c->ev[3], s));
     if (c->T > 0 && !(c->opts.flags & (DAGCON_FLAG_STOP_AFTER_BUILD | DAGCON_FLAG_STOP_AFTER_MERGE))) {
         hipLaunchKernelGGL(k_bp_terms, dim3(c->T, 16), dim3(256), 0, s, p);
-        hipLaunchKernelGGL(k_bp_prepare, dim3(c->T, 16), dim3(256), 0, s, p);
         hipLaunchKernelGGL(k_bp_sweep, dim3(c->T * c->seg_max), dim3(64), 0, s, p);
         hipLaunchKernelGGL(k_bp_check, dim3(c->T), dim3(64), 0, s, p);
         hipLaunchKernelGGL(k_bp_walk, dim3(c->T * c->seg_max), dim3(64), 0, s, p);

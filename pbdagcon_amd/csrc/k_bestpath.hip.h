@@ -12,8 +12,8 @@
 // that does not depend on any score.
 //
 //   k_bp_terms    thread per vertex: the target-side term of w(e), one float per vertex.
-//   k_bp_prepare  thread per vertex, whole chip: w(e) for every out edge, written over the
-//                 edge count in the out list (the counts are not needed any more).
+//                 (w(e) itself is formed from it and the edge's count when k_bp_sweep unpacks a
+//                 chunk: the terms are gathered a chunk ahead, like the edges.)
 //   k_bp_sweep    one wave per (target, segment between two cut vertices of k_cuts); what
 //                 is left is the bare recurrence.  Vertex ids
 //                 are in backbone-position order, a topological order except for the few
@@ -63,28 +63,6 @@ __global__ __launch_bounds__(256) void k_bp_terms(DgParams p) {
     }
 }
 
-__global__ __launch_bounds__(256) void k_bp_prepare(DgParams p) {
-    const uint32_t t = blockIdx.x;
-    if (dg_failed(p) || !p.tactive[t]) return;
-    const uint64_t nb = p.node_base[t];
-    const uint32_t N = p.n_nodes[t];
-    const float *tt = p.bp_tt + nb;
-    uint32_t *pool = p.pool + p.pool_base[t];
-    const DgNode *nd = p.nodes + nb;
-    for (uint32_t v = blockIdx.y * 256 + threadIdx.x; v < N; v += gridDim.y * 256) {
-        const uint32_t hx = *reinterpret_cast<const uint32_t *>(&nd[v]);
-        const uint32_t out_off = nd[v].out_off;
-        const uint32_t out_len = hx & 0xffffu;
-        for (uint32_t i = 0; i < out_len; i++) {
-            const uint32_t d = pool[out_off + 2 * i];
-            const int cnt = (int)pool[out_off + 2 * i + 1];
-            const float x = tt[d];
-            const float w = x == DG_TT_TEN ? -10.0f : (float)cnt - x;     // :404-408
-            pool[out_off + 2 * i + 1] = __float_as_uint(w);
-        }
-    }
-}
-
 // LDS per sweep wave is what bounds the waves in flight (8 segments x 1000 targets want
 // ~8 KB each): only the chunk being swept needs its edges staged, and successors are
 // almost always within a few hundred ids
@@ -122,7 +100,7 @@ struct DgWalkShared {
 // score 0 and is not evaluated, so the scores are relative to it.  amax = largest
 // |score| seen.
 __device__ __forceinline__ void dg_bp_sweep(DgBpShared &S, const DgNode *nd, int32_t *best, float2 *score,
-                                            const uint32_t *pool, const int v_top, const int v_bot,
+                                            const uint32_t *pool, const float *tt, const int v_top, const int v_bot,
                                             const int c_top, int32_t *gstk, const int gstk_cap,
                                             const int lane, float &amax, bool &bad, bool &stuck) {
     for (int i = lane; i < DG_SR; i += 64) S.stag[i] = -1;
@@ -131,7 +109,8 @@ __device__ __forceinline__ void dg_bp_sweep(DgBpShared &S, const DgNode *nd, int
 
     // ---- staging registers: r_* = records of a chunk, e_* = its edges ----
     uint4 r_lo, r_hi, n_lo, n_hi;
-    int e_dst[DG_BOUT], e_w[DG_BOUT];
+    int e_dst[DG_BOUT], e_w[DG_BOUT];          // e_w: the edge's count; its score term is made of it and
+    float e_t[DG_BOUT];                        // e_t, the target-side term (k_bp_terms), when the chunk is unpacked
     // chunk c holds ids [v_top-64c-63, v_top-64c]; lane l -> id v_top-64c-l
 #define DG_LOAD_REC(C, LO, HI)                                                             \
     do {                                                                                    \
@@ -150,6 +129,10 @@ __device__ __forceinline__ void dg_bp_sweep(DgBpShared &S, const DgNode *nd, int
             if (ol_ <= DG_BOUT && k_ < ol_) { e_dst[k_] = (int)pool[(HI).x + 2 * k_]; e_w[k_] = (int)pool[(HI).x + 2 * k_ + 1]; } \
         }                                                                                   \
     } while (0)
+#define DG_LOAD_TT()                                                                        \
+    do {                                                                                    \
+        _Pragma("unroll") for (int k_ = 0; k_ < DG_BOUT; k_++) e_t[k_] = tt[e_dst[k_]];     \
+    } while (0)
 #define DG_WRITE_CHUNK(C, LO)                                                               \
     do {                                                                                    \
         const int v_ = v_top - 64 * (C) - lane;                                             \
@@ -162,7 +145,7 @@ __device__ __forceinline__ void dg_bp_sweep(DgBpShared &S, const DgNode *nd, int
             if (ol_ <= DG_BOUT) {                                                           \
                 _Pragma("unroll") for (int k_ = 0; k_ < DG_BOUT; k_++) {                    \
                     S.out_dst[x_ * DG_BOUT + k_] = e_dst[k_];                               \
-                    S.out_w[x_ * DG_BOUT + k_] = __int_as_float(e_w[k_]);                   \
+                    S.out_w[x_ * DG_BOUT + k_] = e_t[k_] == DG_TT_TEN ? -10.0f : (float)e_w[k_] - e_t[k_]; /* :404-408 */ \
                 }                                                                           \
             }                                                                               \
         }                                                                                   \
@@ -172,10 +155,12 @@ __device__ __forceinline__ void dg_bp_sweep(DgBpShared &S, const DgNode *nd, int
     // prologue: chunk 0 into the ring; chunk 1 records + edges, chunk 2 records in flight
     DG_LOAD_REC(0, r_lo, r_hi);
     DG_LOAD_ENT(r_lo, r_hi);
+    DG_LOAD_TT();
     DG_WRITE_CHUNK(0, r_lo);
     DG_LOAD_REC(1, r_lo, r_hi);
     DG_LOAD_ENT(r_lo, r_hi);
     DG_LOAD_REC(2, n_lo, n_hi);
+    DG_LOAD_TT();                                      // (chunk 1's; from here on at the end of every chunk)
 
     unsigned long long guard = 0;
     const unsigned long long guard_max = 64ull * (unsigned long long)(v_top - v_bot + 1) + 1000000ull;
@@ -207,6 +192,7 @@ __device__ __forceinline__ void dg_bp_sweep(DgBpShared &S, const DgNode *nd, int
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         return __popcll(hit);
     };
+    bool tt_due = false;
     for (int c = 0; c < n_chunks && !bad; c++) {
         if (c > 0) {
             // chunk c: its records and edges were requested a whole chunk ago
@@ -214,6 +200,7 @@ __device__ __forceinline__ void dg_bp_sweep(DgBpShared &S, const DgNode *nd, int
             r_lo = n_lo; r_hi = n_hi;
             DG_LOAD_ENT(r_lo, r_hi);                       // chunk c+1
             DG_LOAD_REC(c + 2, n_lo, n_hi);                // chunk c+2
+            tt_due = true;
         }
         const int v_hi = v_top - 64 * c;
         const int v_lo = v_hi - 63 < v_bot ? v_bot : v_hi - 63;
@@ -325,7 +312,11 @@ __device__ __forceinline__ void dg_bp_sweep(DgBpShared &S, const DgNode *nd, int
                     float w = 0.0f;
                     if (valid) {
                         if (!hbm) { d = S.out_dst[x * DG_BOUT + idx]; w = S.out_w[x * DG_BOUT + idx]; }
-                        else { d = (int)pool[out_off + 2 * idx]; w = __uint_as_float(pool[out_off + 2 * idx + 1]); }
+                        else {
+                            d = (int)pool[out_off + 2 * idx];
+                            const float td = tt[d];
+                            w = td == DG_TT_TEN ? -10.0f : (float)(int)pool[out_off + 2 * idx + 1] - td;   // :404-408
+                        }
                     }
                     const int y = d & (DG_SR - 1);
                     const int stg = S.stag[y];
@@ -417,9 +408,12 @@ __device__ __forceinline__ void dg_bp_sweep(DgBpShared &S, const DgNode *nd, int
                 if (S.lens[xr] & DG_BL_DONE) { score[id] = make_float2(S.rscore[xr], 1.0f); best[id] = S.rbest[xr]; }
             }
         }
+        // the target terms of the edges that wait in e_* (requested a chunk ago: they are here)
+        if (tt_due) { DG_LOAD_TT(); tt_due = false; }
     }
 #undef DG_LOAD_REC
 #undef DG_LOAD_ENT
+#undef DG_LOAD_TT
 #undef DG_WRITE_CHUNK
 }
 
@@ -443,7 +437,7 @@ __global__ __launch_bounds__(64) void k_bp_sweep(DgParams p) {
     const int c_top = seg + 1 < nseg ? (int)crow[2 + seg] : -1;
     float amax = 0.0f;
     bool bad = false, stuck = false;
-    dg_bp_sweep(S, p.nodes + nb, p.best + nb, p.score + nb, p.pool + p.pool_base[t],
+    dg_bp_sweep(S, p.nodes + nb, p.best + nb, p.score + nb, p.pool + p.pool_base[t], p.bp_tt + nb,
                 c_top >= 0 ? c_top - 1 : N - 1, c_bot, c_top,
                 p.stk + (uint64_t)blockIdx.x * p.stk_words, (int)p.stk_words, lane, amax, bad, stuck);
     if (bad) {                                                    // STACK: the host grows the scratch and re-runs
@@ -487,7 +481,7 @@ __global__ __launch_bounds__(64) void k_bp_check(DgParams p) {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     float amax = 0.0f;
     bool bad = false, stuck = false;
-    dg_bp_sweep(S, p.nodes + nb, p.best + nb, score, p.pool + p.pool_base[t], N - 1, 0, -1,
+    dg_bp_sweep(S, p.nodes + nb, p.best + nb, score, p.pool + p.pool_base[t], p.bp_tt + nb, N - 1, 0, -1,
                 p.stk + (uint64_t)t * p.seg_max * p.stk_words, (int)p.stk_words, lane, amax, bad, stuck);
     if (bad && lane == 0) { dg_fail(p, stuck ? DG_E_INTERNAL : DG_E_STACK); p.st->bad_target = t; }
 }
