@@ -235,10 +235,7 @@ int launch_all(Ctx *c) {
     HIPCHK(c, hipEventRecord(c->ev[0], s));
     launch_normalize(c, p);
     HIPCHK(c, hipEventRecord(c->ev[1], s));
-    if (c->mat_cells) {
-        HIPCHK(c, hipMemsetAsync(c->d_matA.p, 0, c->mat_cells * 4, s));
-        HIPCHK(c, hipMemsetAsync(c->d_matD.p, 0, c->mat_cells * 4, s));
-    }
+    // (matA / matD are not cleared: k_emit writes every cell of every row)
     hipLaunchKernelGGL(k_carve, dim3(1), dim3(1024), 0, s, p);
     if (c->T > 0) {
         const uint32_t rows4 = (c->max_tlen + 2 + 4 * DG_LPW - 1) / (4 * DG_LPW);   // 4 waves x DG_LPW positions per block

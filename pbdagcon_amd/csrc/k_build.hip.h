@@ -865,11 +865,12 @@ __global__ __launch_bounds__(64) void k_emit(DgParams p) {
         }                                                                    \
     } while (0)
 
-    // first position of the wave (a multiple of 4 below it, for the 16-byte bid loads)
-    uint32_t pos0 = done ? 0xFFFFFFFFu : bbpos;
-    for (int o = 32; o > 0; o >>= 1) { const uint32_t x = (uint32_t)__shfl_xor((int)pos0, o); pos0 = x < pos0 ? x : pos0; }
-    pos0 &= ~3u;                                   // bbv_base is a multiple of 4 (and so is P0 <= pos0)
-    while (!__all(done) && pos0 < P1 && pos0 <= blen + 2u * DG_EB) {   // (every read ends by position tlen + 1)
+    // Every row of the stretch is written (cells no read touches as zeros), so the matrices need no
+    // clearing beforehand: the wave starts at the stretch's first position whether or not a read of
+    // its is there yet, and goes on to its end (and past position tlen while a read still has to
+    // reach the exit: every read ends by position tlen + 1).
+    uint32_t pos0 = P0;                            // a multiple of 16
+    while (pos0 < P1 && (pos0 <= blen || (!__all(done) && pos0 <= blen + 2u * DG_EB))) {
         // backbone ids of the batch: bid[pos0 .. pos0+15] (reads past tlen+1 stay inside the arena)
         uint32_t bidv[DG_EB];
         {
