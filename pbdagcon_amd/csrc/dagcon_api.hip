@@ -1,7 +1,7 @@
 // dagcon_api.hip -- host side of the C ABI (include/dagcon.h).
 //
 // Owns the HIP stream, the HBM arenas and the launch sequence of the hot path
-//   a1 k_count, k_norm_*    | a2 k_carve, k_groups, k_emit, k_lists |
+//   a1 k_norm_*             | a2 k_carve, k_groups, k_emit, k_lists |
 //   b  k_merge              | c  k_bestpath
 // There is no CPU fallback anywhere in this file: without a HIP device
 // dagcon_create fails with DAGCON_ERR_NO_DEVICE.
@@ -46,6 +46,7 @@ struct Ctx {
     uint64_t matc_cells = 0;
     std::vector<uint8_t> h_tactive;
     std::vector<uint32_t> h_ch_base, h_ch_aln;      // chunk tables of k_norm_*
+    std::vector<uint64_t> h_norm_off;               // column buffer of each alignment
     std::vector<uint32_t> h_ck_base;                // first k_emit checkpoint of each alignment
     uint64_t n_ckpt = 0;
     uint32_t emit_shift = 9;                        // 512 backbone positions per k_emit wave
@@ -214,7 +215,6 @@ void launch_normalize(Ctx *c, const DgParams &p) {
     hipStream_t s = c->stream;
     if (c->A == 0) return;
     (void)hipMemsetAsync(c->d_ckpt.p, 0xFF, c->n_ckpt * 4, s);
-    hipLaunchKernelGGL(k_count, dim3(c->A), dim3(256), 0, s, p);
     hipLaunchKernelGGL((k_norm_chunk<DG_NW, 64, false>), dim3((c->n_chunks + 63) / 64), dim3(64), 0, s, p);
     hipLaunchKernelGGL((k_norm_chunk<DG_NW_BIG, 32, true>), dim3((c->n_chunks + 31) / 32), dim3(32), 0, s, p);
     hipLaunchKernelGGL(k_norm_scan, dim3((c->A + 63) / 64), dim3(64), 0, s, p);
@@ -422,6 +422,14 @@ int dagcon_upload(dagcon_ctx *ctx, const dagcon_batch *b) {
         if (c->h_ch_aln.size() + nw > 0xFFFFFFF0ull) return fail(c, DAGCON_ERR_UNSUPPORTED, "too many alignment columns");
         c->h_ch_aln.insert(c->h_ch_aln.end(), nw, a);
     }
+    // column buffers: an alignment normalises to at most 2 columns per input column (every mismatch
+    // becomes two); offsets are multiples of 8 columns (16-byte pieces)
+    c->h_norm_off.assign((size_t)c->A, 0);
+    {
+        uint64_t top = 0;
+        for (uint32_t a = 0; a < c->A; a++) { c->h_norm_off[a] = top; top += (2ull * c->h_aln_len[a] + 7ull) & ~7ull; }
+        c->norm_cap = std::max<uint64_t>(c->norm_cap, top + 64);
+    }
     c->h_ck_base.assign((size_t)c->A, 0);
     c->n_ckpt = 0;
     for (uint32_t a = 0; a < c->A; a++) {
@@ -461,11 +469,12 @@ int dagcon_upload(dagcon_ctx *ctx, const dagcon_batch *b) {
     if ((r = upload_vec(c, c->d_ch_base, c->h_ch_base))) return r;
     if ((r = upload_vec(c, c->d_ch_aln, c->h_ch_aln))) return r;
     if ((r = upload_vec(c, c->d_ck_base, c->h_ck_base))) return r;
+    if ((r = upload_vec(c, c->d_norm_off, c->h_norm_off))) return r;
     ENSURE(c, c->d_ckpt, c->n_ckpt * 4);
 
     // work arrays whose size the host knows
     const size_t A4 = (size_t)c->A * 4, T4 = (size_t)T * 4;
-    ENSURE(c, c->d_nmis, A4); ENSURE(c, c->d_norm_off, (size_t)c->A * 8);
+    ENSURE(c, c->d_nmis, A4);
     ENSURE(c, c->d_n_lo, A4); ENSURE(c, c->d_n_hi, A4); ENSURE(c, c->d_n_start, A4);
     ENSURE(c, c->d_n_ins, A4); ENSURE(c, c->d_n_del, A4); ENSURE(c, c->d_n_lb, A4);
     {
@@ -486,7 +495,6 @@ int dagcon_upload(dagcon_ctx *ctx, const dagcon_batch *b) {
 
     // first guesses for the data-dependent arenas; a run that finds them too
     // small records the exact need on the device and is repeated once.
-    c->norm_cap = std::max<uint64_t>(c->norm_cap, c->sum_len + c->sum_len / 32 + 8ull * c->A + 1024);
     c->node_cap = std::max<uint64_t>(c->node_cap, c->sum_bb + c->sum_len / 7 + 1024);
     c->pool_cap = std::max<uint64_t>(c->pool_cap, 8ull * c->node_cap + 80ull * c->sum_bb + 1024ull * T);
     c->cns_cap = std::max<uint64_t>(c->cns_cap, c->sum_bb + c->sum_bb / 4 + 1024);

@@ -1,6 +1,5 @@
 // k_build.hip.h -- stage (a): alignment strings -> alignment DAG in HBM.
 //
-//   k_count      a1  mismatch count per alignment (sizes the column buffer), byte validation
 //   k_norm_*     a1  normalizeGaps (Alignment.cpp:131-217) + trimAln (:219-242) in chunks of ~1 k
 //                    input columns, one lane per chunk; also records the insertion run length
 //                    per (position, read).  k_normalize_slow: whole alignments, sequential.
@@ -26,43 +25,6 @@ __device__ __forceinline__ bool dg_failed(const DgParams &p) {
 }
 __device__ __forceinline__ void dg_fail(const DgParams &p, uint32_t bit) {
     atomicOr(&p.st->err_flags, bit);
-}
-
-// ---------------------------------------------------------------------------
-// k_count: one 256-thread block per alignment.
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_count(DgParams p) {
-    const uint32_t a = blockIdx.x;
-    if (a >= p.A) return;
-    const uint64_t off = p.aln_off[a];
-    const uint32_t len = p.aln_len[a];
-    const uint8_t *q = p.q + off, *t = p.t + off;
-    uint32_t mis = 0, bad = 0;
-    for (uint32_t i = threadIdx.x; i < len; i += 256) {
-        uint8_t qb = q[i], tb = t[i];
-        bad |= (qb < 33 || qb > 126 || tb < 33 || tb > 126);
-        if (qb == '.') qb = DG_GAP;
-        if (tb == '.') tb = DG_GAP;
-        mis += (qb != tb && qb != DG_GAP && tb != DG_GAP);
-    }
-    for (int o = 32; o > 0; o >>= 1) {
-        mis += __shfl_down(mis, o);
-        bad |= __shfl_down(bad, o);
-    }
-    __shared__ uint32_t s_mis[4], s_bad[4];
-    if ((threadIdx.x & 63) == 0) { s_mis[threadIdx.x >> 6] = mis; s_bad[threadIdx.x >> 6] = bad; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        mis = s_mis[0] + s_mis[1] + s_mis[2] + s_mis[3];
-        bad = s_bad[0] | s_bad[1] | s_bad[2] | s_bad[3];
-        if (p.flags & DG_F_RAW) mis = 0;   // raw mode: columns are taken as they are
-        if (bad) { dg_fail(p, DG_E_BADCHAR); p.st->bad_aln = a; }
-        p.nmis[a] = mis;
-        unsigned long long cap = ((unsigned long long)len + mis + 7ull) & ~7ull;
-        unsigned long long o = atomicAdd(&p.st->norm_top, cap);
-        p.norm_off[a] = o;
-        if (o + cap > p.norm_cap) dg_fail(p, DG_E_NORM_OVF);
-    }
 }
 
 // ---------------------------------------------------------------------------
@@ -193,7 +155,7 @@ __device__ inline uint32_t dg_chunk_start(const uint8_t *q, const uint8_t *t, ui
     return DG_CH_NONE;
 }
 
-struct DgChunkRun { uint32_t w, tb; bool dirty, overflow; };
+struct DgChunkRun { uint32_t w, tb; bool dirty, overflow, badchar; };
 
 // normalizeGaps (Alignment.cpp:142-214) on the input columns [k0, k1) of an alignment, started
 // cold; the look-ahead may read (and, reported as `dirty`, write) beyond k1.
@@ -202,8 +164,9 @@ __device__ inline DgChunkRun dg_norm_run(const uint8_t *q, const uint8_t *t, con
                                          const uint32_t k1, uint16_t *win, uint16_t *out) {
 #define DG_W(x) win[(x) & (NW - 1u)]
     DgChunkRun r;
-    r.w = 0; r.tb = 0; r.dirty = false; r.overflow = false;
+    r.w = 0; r.tb = 0; r.dirty = false; r.overflow = false; r.badchar = false;
     if (k0 >= k1) return r;
+    uint32_t badw = 0;                                     // bit 7 of a byte set: a byte outside 33..126 was read
     uint32_t ip = k0, e = 0, i = 0, w = 0, tb = 0, jt = 0, jq = 0;
     uint32_t e_end = 0xFFFFFFFFu;                          // window index of input column k1, once known
     // finished columns collect in a 128-bit shift register and leave 8 at a time (out is
@@ -235,6 +198,12 @@ __device__ inline DgChunkRun dg_norm_run(const uint8_t *q, const uint8_t *t, con
                 const uint4 qv = *reinterpret_cast<const uint4 *>(q + ip);
                 const uint4 tv = *reinterpret_cast<const uint4 *>(t + ip);
                 const uint32_t qw[4] = {qv.x, qv.y, qv.z, qv.w}, tw[4] = {tv.x, tv.y, tv.z, tv.w};
+                // every byte has to be printable ASCII (33..126): four at a time
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    badw |= ((qw[k] - 0x21212121u) & ~qw[k]) | ((qw[k] + 0x01010101u) | qw[k]);
+                    badw |= ((tw[k] - 0x21212121u) & ~tw[k]) | ((tw[k] + 0x01010101u) | tw[k]);
+                }
 #pragma unroll
                 for (int k = 0; k < 16; k++)
                     DG_EXPAND((uint8_t)(qw[k >> 2] >> (8 * (k & 3))), (uint8_t)(tw[k >> 2] >> (8 * (k & 3))));
@@ -242,7 +211,11 @@ __device__ inline DgChunkRun dg_norm_run(const uint8_t *q, const uint8_t *t, con
                 // head (up to the next 16-byte boundary) and tail: byte loads
                 const uint32_t to_align = (uint32_t)((16u - (((uintptr_t)(q + ip)) & 15u)) & 15u);
                 if (to_align && take > to_align) take = to_align;
-                for (uint32_t k = 0; k < take; k++) DG_EXPAND(q[ip + k], t[ip + k]);
+                for (uint32_t k = 0; k < take; k++) {
+                    const uint8_t qb0 = q[ip + k], tb0 = t[ip + k];
+                    if (qb0 < 33 || qb0 > 126 || tb0 < 33 || tb0 > 126) badw = 0x80u;
+                    DG_EXPAND(qb0, tb0);
+                }
             }
 #undef DG_EXPAND
             ip += take;
@@ -297,7 +270,7 @@ __device__ inline DgChunkRun dg_norm_run(const uint8_t *q, const uint8_t *t, con
         const uint32_t v = word == 0 ? o0 : word == 1 ? o1 : word == 2 ? o2 : o3;
         out[x] = (uint16_t)((sh & 1u) ? v >> 16 : v & 0xffffu);
     }
-    r.w = w; r.tb = tb; r.dirty = dirty;
+    r.w = w; r.tb = tb; r.dirty = dirty; r.badchar = (badw & 0x80808080u) != 0;
     return r;
 }
 
@@ -321,7 +294,7 @@ __global__ __launch_bounds__(LANES) void k_norm_chunk(DgParams p) {
     const uint8_t *q = p.q + off, *t = p.t + off;
     uint32_t flag = 0;
     DgChunkRun r;
-    r.w = 0; r.tb = 0; r.dirty = false; r.overflow = false;
+    r.w = 0; r.tb = 0; r.dirty = false; r.overflow = false; r.badchar = false;
     uint32_t k0 = DG_CH_NONE, cn = c + 1;
     uint64_t src = 0;
     if (p.flags & DG_F_RAW) {                              // raw columns: the slow kernel copies them
@@ -338,6 +311,7 @@ __global__ __launch_bounds__(LANES) void k_norm_chunk(DgParams p) {
                     if (s != DG_CH_NONE) { k1 = s; break; }
                 }
                 r = dg_norm_run<NW>(q, t, len, k0, k1, win, p.norm_tmp + src);
+                if (r.badchar) { dg_fail(p, DG_E_BADCHAR); p.st->bad_aln = a; }
                 if (r.overflow) { flag = RETRY ? 1u : 2u; break; }
                 if (!r.dirty) break;
                 // a gap in flight got past the end: once more with the next chunk taken in,
@@ -532,6 +506,7 @@ __global__ __launch_bounds__(64) void k_normalize_slow(DgParams p) {
     uint32_t n = 0;
     for (uint32_t i = 0; i < len; i++) {
         uint8_t qb = q[i], tb = t[i];
+        if (qb < 33 || qb > 126 || tb < 33 || tb > 126) { dg_fail(p, DG_E_BADCHAR); p.st->bad_aln = a; }
         if (!raw) {
             if (qb == '.') qb = DG_GAP;
             if (tb == '.') tb = DG_GAP;

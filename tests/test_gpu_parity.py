@@ -337,6 +337,18 @@ def test_nonconforming_is_rejected(gpu_ctx_factory):
     with pytest.raises(capi.DagconError) as e:
         ctx.consensus(batch_from_targets([(5, [(1, b"AC\x01TA", b"ACGTA")], b"NNNNN")]))
     assert e.value.code == -4
+    # ... anywhere in a long alignment (the 16-byte path of the chunked normalize), in either string,
+    # just outside the range on both sides; and in raw mode (k_normalize_slow)
+    good = bytes(b"ACGT"[i % 4] for i in range(3000))
+    for pos, byte, in_q in ((1500, 0x20, True), (1501, 0x7F, False), (2999, 0x80, True), (7, 0xFF, False)):
+        bad = bytearray(good); bad[pos] = byte
+        q, t = (bytes(bad), good) if in_q else (good, bytes(bad))
+        for flags in (0, capi.FLAG_RAW_ALIGNMENTS):
+            c2 = gpu_ctx_factory(min_cov=0, min_len=0, trim=0, min_weight=0, flags=flags)
+            with pytest.raises(capi.DagconError) as e:
+                c2.consensus(batch_from_targets([(3000, [(1, q, t)], b"N" * 3000)]))
+            assert e.value.code == -4, (pos, byte, in_q, flags)
+    assert e.value.code == -4
     # the context is still usable afterwards
     ok = ctx.consensus(batch_from_targets([(5, [(1, b"ACGTA", b"ACGTA")], b"NNNNN")]))
     assert ok[0] == [(0, 5, b"ACGTA")]
