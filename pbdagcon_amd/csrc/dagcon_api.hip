@@ -62,11 +62,11 @@ struct Ctx {
     DevBuf d_node_base, d_n_nodes, d_pool_base, d_pool_size, d_pool_top, d_t_nins;
     DevBuf d_matA, d_matD, d_matC, d_cov, d_gcount, d_gbase, d_bid;
     DevBuf d_nodes, d_best, d_queue, d_score, d_cns_tmp, d_bp_tt;
-    DevBuf d_pool, d_stk, d_cuts, d_bp_stat, d_bp_len;
+    DevBuf d_pool, d_stk, d_cuts, d_cuts_bp, d_bp_stat, d_bp_len;
     DevBuf d_cns, d_cns_off, d_cns_len, d_seg_first, d_n_seg, d_seg_r0, d_seg_r1, d_st;
 
     uint64_t norm_cap = 0, node_cap = 0, pool_cap = 0, cns_cap = 0, seg_cap = 0;
-    uint32_t stk_words = 4096, growth_pct = 100, seg_max = 8, seg_env = 0;    // (scratch per target and segment: grown x4 and re-run on DG_E_STACK)
+    uint32_t stk_words = 4096, growth_pct = 100, seg_max = 8, bp_max = 16, seg_env = 0;    // (scratch per target and segment: grown x4 and re-run on DG_E_STACK)
     uint64_t expected_workers = 0;                  // merge workers the batch will probably run (prefetch on / off)
 
     DgStatus h_st;
@@ -143,10 +143,11 @@ int ensure_arenas(Ctx *c) {
     ENSURE(c, c->d_bp_tt, c->node_cap * 4);
     ENSURE(c, c->d_cns_tmp, c->node_cap);
     ENSURE(c, c->d_pool, c->pool_cap * 4);
-    ENSURE(c, c->d_stk, (uint64_t)c->T * c->seg_max * c->stk_words * 4);
+    ENSURE(c, c->d_stk, (uint64_t)c->T * c->bp_max * c->stk_words * 4);       // (bp_max >= seg_max)
     ENSURE(c, c->d_cuts, (uint64_t)c->T * (c->seg_max + 2) * 4);
-    ENSURE(c, c->d_bp_stat, (uint64_t)c->T * c->seg_max * 8);
-    ENSURE(c, c->d_bp_len, (uint64_t)c->T * c->seg_max * 4);
+    ENSURE(c, c->d_cuts_bp, (uint64_t)c->T * (c->bp_max + 2) * 4);
+    ENSURE(c, c->d_bp_stat, (uint64_t)c->T * c->bp_max * 8);
+    ENSURE(c, c->d_bp_len, (uint64_t)c->T * c->bp_max * 4);
     ENSURE(c, c->d_cns, c->cns_cap);
     ENSURE(c, c->d_seg_r0, c->seg_cap * 4);
     ENSURE(c, c->d_seg_r1, c->seg_cap * 4);
@@ -201,7 +202,7 @@ void fill_params(Ctx *c, DgParams &p) {
     // the prefetch wave pays while the chip has idle wave slots; past ~1.5 workers per SIMD the
     // workers hide each other's latency and it only takes issue slots from them
     { const char *e = getenv("DAGCON_PF_AHEAD"); p.pf_ahead = e ? (uint32_t)atoi(e) : (c->expected_workers >= 4096 ? 0u : 48u); }
-    p.seg_max = c->seg_max; p.seg_min = c->opts.min_segment_len ? c->opts.min_segment_len : 768u; p.cuts = (uint32_t *)c->d_cuts.p; p.bp_stat = (float *)c->d_bp_stat.p; p.bp_len = (uint32_t *)c->d_bp_len.p;
+    p.seg_max = c->seg_max; p.seg_min = c->opts.min_segment_len ? c->opts.min_segment_len : 768u; p.cuts = (uint32_t *)c->d_cuts.p; p.bp_max = c->bp_max; p.cuts_bp = (uint32_t *)c->d_cuts_bp.p; p.bp_stat = (float *)c->d_bp_stat.p; p.bp_len = (uint32_t *)c->d_bp_len.p;
     p.cns = (uint8_t *)c->d_cns.p; p.cns_cap = c->cns_cap;
     p.cns_off = (uint64_t *)c->d_cns_off.p; p.cns_len = (uint32_t *)c->d_cns_len.p;
     p.seg_first = (uint64_t *)c->d_seg_first.p; p.n_seg = (uint32_t *)c->d_n_seg.p;
@@ -258,9 +259,9 @@ int launch_all(Ctx *c) {
     HIPCHK(c, hipEventRecord(c->ev[3], s));
     if (c->T > 0 && !(c->opts.flags & (DAGCON_FLAG_STOP_AFTER_BUILD | DAGCON_FLAG_STOP_AFTER_MERGE))) {
         hipLaunchKernelGGL(k_bp_terms, dim3(c->T, 16), dim3(256), 0, s, p);
-        hipLaunchKernelGGL(k_bp_sweep, dim3(c->T * c->seg_max), dim3(64), 0, s, p);
+        hipLaunchKernelGGL(k_bp_sweep, dim3(c->T * c->bp_max), dim3(64), 0, s, p);
         hipLaunchKernelGGL(k_bp_check, dim3(c->T), dim3(64), 0, s, p);
-        hipLaunchKernelGGL(k_bp_walk, dim3(c->T * c->seg_max), dim3(64), 0, s, p);
+        hipLaunchKernelGGL(k_bp_walk, dim3(c->T * c->bp_max), dim3(64), 0, s, p);
         hipLaunchKernelGGL(k_bp_join, dim3(c->T), dim3(64), 0, s, p);
     }
     HIPCHK(c, hipEventRecord(c->ev[4], s));
@@ -325,7 +326,7 @@ void dagcon_destroy(dagcon_ctx *ctx) {
                      &c->d_n_ins, &c->d_n_del, &c->d_norm, &c->d_node_base, &c->d_n_nodes,
                      &c->d_pool_base, &c->d_pool_size, &c->d_pool_top, &c->d_t_nins, &c->d_matA, &c->d_matD,
                      &c->d_matC, &c->d_cov, &c->d_gcount, &c->d_gbase, &c->d_bid, &c->d_nodes,
-                     &c->d_best, &c->d_queue, &c->d_score, &c->d_cns_tmp, &c->d_bp_tt, &c->d_pool, &c->d_stk, &c->d_cuts, &c->d_bp_stat, &c->d_bp_len, &c->d_cns,
+                     &c->d_best, &c->d_queue, &c->d_score, &c->d_cns_tmp, &c->d_bp_tt, &c->d_pool, &c->d_stk, &c->d_cuts, &c->d_cuts_bp, &c->d_bp_stat, &c->d_bp_len, &c->d_cns,
                      &c->d_cns_off, &c->d_cns_len, &c->d_seg_first, &c->d_n_seg, &c->d_seg_r0, &c->d_seg_r1,
                      &c->d_st};
     for (DevBuf *b : all) free_buf(*b);
@@ -352,6 +353,10 @@ int dagcon_upload(dagcon_ctx *ctx, const dagcon_batch *b) {
     if (c->opts.max_segments) c->seg_max = c->opts.max_segments > 64u ? 64u : c->opts.max_segments;
     else if (c->seg_env) c->seg_max = c->seg_env;
     else { uint32_t sm = T ? 8192u / T : 8u; c->seg_max = sm < 8u ? 8u : sm > 32u ? 32u : sm; }
+    // bestPath is swept in three times as many pieces: its waves are light (one piece = one
+    // sequential sweep when that is asked for)
+    c->bp_max = c->seg_max == 1 ? 1u : std::min(64u, 3u * c->seg_max);
+    if (const char *e = getenv("DAGCON_BP_SEGS")) { const int v = atoi(e); if (v >= 1 && v <= 64) c->bp_max = (uint32_t)v; }
     c->h_tlen.assign(b->tlen, b->tlen + T);
     c->h_aln_begin.assign(T + 1, 0);
     c->h_tactive.assign(T, 0);

@@ -151,6 +151,8 @@ struct DgParams {
     uint32_t seg_max;              // most segments a target's merge sweep is split into (k_cuts)
     uint32_t seg_min;              // shortest backbone stretch worth a worker of its own
     uint32_t *cuts;                // [T][seg_max + 2]: segment count, first vertex of each segment
+    uint32_t bp_max;               // most segments of a target's bestPath sweep (finer than the merge's:
+    uint32_t *cuts_bp;             //   its waves are light), [T][bp_max + 2] like cuts
     float *bp_stat;                // [T][seg_max][2]: largest |score| of the segment, score of its first vertex
     uint32_t *bp_len;              // [T][seg_max]: vertices of the best path inside the segment (enter / exit excluded)
     // ---- outputs ----

@@ -424,9 +424,9 @@ __device__ __forceinline__ void dg_bp_sweep(DgBpShared &S, const DgNode *nd, int
 // first-maximum choices (all that the consensus uses) are the reference's as long as
 // the arithmetic is exact, which k_bp_check verifies from the figures left here.
 __global__ __launch_bounds__(64) void k_bp_sweep(DgParams p) {
-    const uint32_t t = blockIdx.x / p.seg_max, seg = blockIdx.x % p.seg_max;
+    const uint32_t t = blockIdx.x / p.bp_max, seg = blockIdx.x % p.bp_max;
     if (dg_failed(p) || !p.tactive[t]) return;
-    const uint32_t *crow = p.cuts + (uint64_t)t * (p.seg_max + 2u);
+    const uint32_t *crow = p.cuts_bp + (uint64_t)t * (p.bp_max + 2u);
     const uint32_t nseg = crow[0];
     if (seg >= nseg) return;
     const int lane = threadIdx.x;
@@ -460,7 +460,7 @@ __global__ __launch_bounds__(64) void k_bp_check(DgParams p) {
     // (|w| <= max(10, reads)); if all of that stays below 2^22 both the reference's absolute
     // arithmetic and the relative one of k_bp_sweep are exact and pick the same first maxima.
     // Otherwise the target is swept again in one piece.
-    const uint32_t *crow = p.cuts + (uint64_t)t * (p.seg_max + 2u);
+    const uint32_t *crow = p.cuts_bp + (uint64_t)t * (p.bp_max + 2u);
     const int nseg = (int)crow[0];
     if (nseg <= 1) return;
     bool redo = (p.flags & DG_F_RESWEEP) != 0;
@@ -468,8 +468,8 @@ __global__ __launch_bounds__(64) void k_bp_check(DgParams p) {
     const float wmax = K > 10.0f ? K : 10.0f;
     float acc = 0.0f;
     for (int i = nseg - 1; i >= 0; i--) {
-        const float m = p.bp_stat[2 * ((uint64_t)t * p.seg_max + i)];
-        const float a = p.bp_stat[2 * ((uint64_t)t * p.seg_max + i) + 1];
+        const float m = p.bp_stat[2 * ((uint64_t)t * p.bp_max + i)];
+        const float a = p.bp_stat[2 * ((uint64_t)t * p.bp_max + i) + 1];
         if (!(m + fabsf(acc) + wmax < 4194304.0f)) redo = true;
         acc += a;
     }
@@ -482,7 +482,7 @@ __global__ __launch_bounds__(64) void k_bp_check(DgParams p) {
     float amax = 0.0f;
     bool bad = false, stuck = false;
     dg_bp_sweep(S, p.nodes + nb, p.best + nb, score, p.pool + p.pool_base[t], p.bp_tt + nb, N - 1, 0, -1,
-                p.stk + (uint64_t)t * p.seg_max * p.stk_words, (int)p.stk_words, lane, amax, bad, stuck);
+                p.stk + (uint64_t)t * p.bp_max * p.stk_words, (int)p.stk_words, lane, amax, bad, stuck);
     if (bad && lane == 0) { dg_fail(p, stuck ? DG_E_INTERNAL : DG_E_STACK); p.st->bad_target = t; }
 }
 
@@ -491,9 +491,9 @@ __global__ __launch_bounds__(64) void k_bp_check(DgParams p) {
 // walked by its own wave.  A segment leaves one byte per path vertex in its own stretch of
 // the scratch (ids of a segment are contiguous): the base, bit 7 = weight >= minWeight.
 __global__ __launch_bounds__(64) void k_bp_walk(DgParams p) {
-    const uint32_t t = blockIdx.x / p.seg_max, seg = blockIdx.x % p.seg_max;
+    const uint32_t t = blockIdx.x / p.bp_max, seg = blockIdx.x % p.bp_max;
     if (dg_failed(p) || !p.tactive[t]) return;
-    const uint32_t *crow = p.cuts + (uint64_t)t * (p.seg_max + 2u);
+    const uint32_t *crow = p.cuts_bp + (uint64_t)t * (p.bp_max + 2u);
     const uint32_t nseg = crow[0];
     if (seg >= nseg) return;
     const int lane = threadIdx.x;
@@ -558,12 +558,12 @@ __global__ __launch_bounds__(64) void k_bp_join(DgParams p) {
     if (dg_failed(p) || !p.tactive[t]) return;
     const int lane = threadIdx.x;
     const uint64_t nb = p.node_base[t];
-    const uint32_t *crow = p.cuts + (uint64_t)t * (p.seg_max + 2u);
+    const uint32_t *crow = p.cuts_bp + (uint64_t)t * (p.bp_max + 2u);
     const uint32_t nseg = crow[0];
     __shared__ uint32_t s_off[65], s_c0[64];
     {
         // where each segment's piece of the path goes (seg_max <= 64: one lane per segment)
-        const uint32_t len = (uint32_t)lane < nseg ? p.bp_len[(uint64_t)t * p.seg_max + lane] : 0u;
+        const uint32_t len = (uint32_t)lane < nseg ? p.bp_len[(uint64_t)t * p.bp_max + lane] : 0u;
         uint32_t incl = len;
         for (int o = 1; o < 64; o <<= 1) { const uint32_t up = __shfl_up(incl, o); if (lane >= o) incl += up; }
         s_off[lane] = incl - len;
@@ -573,7 +573,7 @@ __global__ __launch_bounds__(64) void k_bp_join(DgParams p) {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     const uint32_t total = s_off[64];
     const uint8_t *tmp = p.cns_tmp + nb;
-    int32_t *segs = p.stk + (uint64_t)t * p.seg_max * p.stk_words;      // (range0, range1) pairs
+    int32_t *segs = p.stk + (uint64_t)t * p.bp_max * p.stk_words;      // (range0, range1) pairs
     const uint32_t seg_cap = p.stk_words / 2;
     const uint32_t minlen = p.min_len;
     // every maximal run of path vertices with weight >= minWeight that is long enough

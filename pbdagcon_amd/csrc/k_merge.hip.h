@@ -714,29 +714,36 @@ __global__ __launch_bounds__(64) void k_cuts(DgParams p) {
     int kg = 0;
     for (int i = lane; i < en.out_len; i += 64) kg += (int)pool[en.out_off + 2 * i + 1];
     for (int o = 32; o; o >>= 1) kg += __shfl_xor(kg, o);
-    uint32_t want = blen / p.seg_min;
-    if (want > p.seg_max) want = p.seg_max;
-    if (want < 1) want = 1;
-    uint32_t nseg = 1;
-    if (lane == 0) row[1] = 0;
-    for (uint32_t s = 1; s < want; s++) {
-        const uint32_t p0 = 1u + (uint32_t)((uint64_t)s * blen / want);
-        const uint32_t span = blen / want / 2u;          // stays below the next ideal position
-        uint32_t found = 0;
-        for (uint32_t o = 0; o < span && !found; o += 64) {
-            const uint32_t pos = p0 + o + (uint32_t)lane;
-            uint32_t v = 0;
-            bool ok = false;
-            if (o + (uint32_t)lane < span && pos >= 1 && pos <= blen) {
-                v = bid[pos];
-                ok = nd[v].weight - 1 == kg;
+    // two sets of cuts: the merge's (seg_max pieces: heavy waves, about a chip's worth of them) and a
+    // finer one for bestPath (bp_max pieces: light waves)
+    for (int which = 0; which < 2; which++) {
+        const uint32_t smax = which == 0 ? p.seg_max : p.bp_max;
+        uint32_t *out = which == 0 ? row : p.cuts_bp + (uint64_t)t * (p.bp_max + 2u);
+        const uint32_t smin = which == 0 ? p.seg_min : (p.seg_min + 2u) / 3u;
+        uint32_t want = blen / (smin ? smin : 1u);
+        if (want > smax) want = smax;
+        if (want < 1) want = 1;
+        uint32_t nseg = 1;
+        if (lane == 0) out[1] = 0;
+        for (uint32_t s = 1; s < want; s++) {
+            const uint32_t p0 = 1u + (uint32_t)((uint64_t)s * blen / want);
+            const uint32_t span = blen / want / 2u;          // stays below the next ideal position
+            uint32_t found = 0;
+            for (uint32_t o = 0; o < span && !found; o += 64) {
+                const uint32_t pos = p0 + o + (uint32_t)lane;
+                uint32_t v = 0;
+                bool ok = false;
+                if (o + (uint32_t)lane < span && pos >= 1 && pos <= blen) {
+                    v = bid[pos];
+                    ok = nd[v].weight - 1 == kg;
+                }
+                const unsigned long long m = __ballot(ok);
+                if (m) found = (uint32_t)DG_RL(v, __ffsll((long long)m) - 1);
             }
-            const unsigned long long m = __ballot(ok);
-            if (m) found = (uint32_t)DG_RL(v, __ffsll((long long)m) - 1);
+            if (found) { if (lane == 0) out[1 + nseg] = found; nseg++; }
         }
-        if (found) { if (lane == 0) row[1 + nseg] = found; nseg++; }
+        if (lane == 0) { out[0] = nseg; if (which == 0) atomicAdd(&p.st->n_mseg, nseg); }
     }
-    if (lane == 0) { row[0] = nseg; atomicAdd(&p.st->n_mseg, nseg); }
 }
 
 // ---- mergeNodes (AlnGraphBoost.cpp:129-160): one wave per (target, segment) ----
