@@ -181,7 +181,7 @@ def main():
     if rank == 0:
         traffic = None
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01", "v9_pmc_hbm_traffic.json")))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01", "v10_pmc_hbm_traffic.json")))
             if args.targets == 1000 and args.tlen == 10000 and args.coverage == 40:
                 key = [k for k in pmc["kernels"] if k.startswith("k_merge")][0]
                 traffic = pmc["kernels"][key]["hbm_bytes_per_launch_raw"]
@@ -216,7 +216,7 @@ def main():
                 "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                 "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bytes per k_merge "
-                                  "launch at this workload, profiles/r01/v9_pmc_hbm_traffic.json" if traffic else None,
+                                  "launch at this workload, profiles/r01/v10_pmc_hbm_traffic.json" if traffic else None,
                 "algorithmic_bytes_per_launch": alg,
                 "kernel_ms": ms_merge,
                 "pipeline_ms": ms_dev,
