@@ -76,7 +76,8 @@ struct Ctx {
     std::vector<uint64_t> r_seg_begin, r_seq_off, r_cns_off, r_seg_first;
     std::vector<int32_t> r_range0, r_range1, r_tmp0, r_tmp1;
     std::vector<uint32_t> r_seq_len, r_cns_len, r_n_seg;
-    std::vector<char> r_blob;
+    char *r_blob = nullptr;             // page-locked: the consensus blob comes back at PCIe speed
+    size_t r_blob_cap = 0;
 
     // debug dump storage
     std::vector<uint8_t> g_base, g_deleted, g_backbone;
@@ -320,6 +321,7 @@ void dagcon_destroy(dagcon_ctx *ctx) {
     Ctx *c = reinterpret_cast<Ctx *>(ctx);
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->r_blob) (void)hipHostFree(c->r_blob);
     DevBuf *all[] = {&c->d_q, &c->d_t, &c->d_aln_off, &c->d_aln_len, &c->d_aln_start, &c->d_aln_tgt,
                      &c->d_tlen, &c->d_aln_begin, &c->d_tactive, &c->d_bb, &c->d_bb_off, &c->d_mat_base, &c->d_matc_base, &c->d_matc_stride,
                      &c->d_bbv_base, &c->d_nmis, &c->d_norm_off, &c->d_n_lo, &c->d_n_hi, &c->d_n_start, &c->d_ch_aln, &c->d_ch_base, &c->d_ch_k0, &c->d_ch_next, &c->d_ch_w, &c->d_ch_tb, &c->d_ch_flag, &c->d_ch_src, &c->d_ch_out, &c->d_ch_adv, &c->d_n_lb, &c->d_norm_tmp, &c->d_ckpt, &c->d_ck_base,
@@ -579,7 +581,14 @@ int dagcon_fetch(dagcon_ctx *ctx, dagcon_results *res) {
     const uint64_t nseg = c->h_st.seg_top, nb = c->h_st.cns_top;
     c->r_cns_off.assign(T, 0); c->r_cns_len.assign(T, 0); c->r_seg_first.assign(T, 0); c->r_n_seg.assign(T, 0);
     c->r_tmp0.assign(nseg, 0); c->r_tmp1.assign(nseg, 0);
-    c->r_blob.assign(nb + 1, 0);
+    if (c->r_blob_cap < nb + 1) {
+        if (c->r_blob) (void)hipHostFree(c->r_blob);
+        c->r_blob = nullptr; c->r_blob_cap = 0;
+        const size_t want = (size_t)(nb + 1) + (size_t)(nb / 8) + 4096;
+        HIPCHK(c, hipHostMalloc((void **)&c->r_blob, want, hipHostMallocDefault));
+        c->r_blob_cap = want;
+    }
+    c->r_blob[nb] = 0;
     const bool full = !(c->opts.flags & (DAGCON_FLAG_STOP_AFTER_BUILD | DAGCON_FLAG_STOP_AFTER_MERGE));
     if (T && full) {
         HIPCHK(c, hipMemcpy(c->r_cns_off.data(), c->d_cns_off.p, (size_t)T * 8, hipMemcpyDeviceToHost));
@@ -590,7 +599,7 @@ int dagcon_fetch(dagcon_ctx *ctx, dagcon_results *res) {
             HIPCHK(c, hipMemcpy(c->r_tmp0.data(), c->d_seg_r0.p, nseg * 4, hipMemcpyDeviceToHost));
             HIPCHK(c, hipMemcpy(c->r_tmp1.data(), c->d_seg_r1.p, nseg * 4, hipMemcpyDeviceToHost));
         }
-        if (nb) HIPCHK(c, hipMemcpy(c->r_blob.data(), c->d_cns.p, nb, hipMemcpyDeviceToHost));
+        if (nb) HIPCHK(c, hipMemcpy(c->r_blob, c->d_cns.p, nb, hipMemcpyDeviceToHost));
     }
     c->r_seg_begin.assign(T + 1, 0);
     c->r_range0.clear(); c->r_range1.clear(); c->r_seq_off.clear(); c->r_seq_len.clear();
@@ -619,7 +628,7 @@ int dagcon_fetch(dagcon_ctx *ctx, dagcon_results *res) {
     res->seg_begin = c->r_seg_begin.data();
     res->range0 = c->r_range0.data(); res->range1 = c->r_range1.data();
     res->seq_off = c->r_seq_off.data(); res->seq_len = c->r_seq_len.data();
-    res->seq_blob = c->r_blob.data(); res->seq_bytes = nb;
+    res->seq_blob = c->r_blob; res->seq_bytes = nb;
     c->fetched = true;
     return DAGCON_OK;
 }
