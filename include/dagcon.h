@@ -67,10 +67,10 @@ typedef struct dagcon_opts {
     int32_t  min_weight; /* consensus minWeight; <0 means "= min_cov" as main.cpp:261,279 does */
     int32_t  device;     /* HIP device ordinal */
     uint32_t flags;
-    uint32_t max_segments; /* workers per target for mergeNodes/bestPath: a target is swept in up to
-                              this many pieces, split at backbone vertices every read passes
-                              through (the result does not depend on it).  0 = automatic,
-                              1 = one sequential sweep per target, at most 64 */
+    uint32_t max_segments; /* workers per target for mergeNodes (bestPath: three times as many): a
+                              target is swept in up to this many pieces, split at backbone vertices
+                              every read passes through (the result does not depend on it).
+                              0 = automatic, 1 = one sequential sweep per target, at most 64 */
     uint32_t min_segment_len; /* shortest backbone stretch given a worker of its own; 0 = default (768) */
 } dagcon_opts;
 
