@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DAGCON_ABI_VERSION 1
+#define DAGCON_ABI_VERSION 2   /* 2: per-target status in dagcon_results, dagcon_host_alloc/free */
 
 typedef enum dagcon_status {
     DAGCON_OK = 0,
@@ -41,7 +41,8 @@ typedef enum dagcon_status {
     DAGCON_ERR_NONCONFORMING = -4,  /* an alignment would drive the reference into undefined
                                        behaviour (AlnGraphBoost.cpp:64-107: start < 1, target bases
                                        past tlen, bytes outside printable ASCII) */
-    DAGCON_ERR_UNSUPPORTED = -5,    /* more alignments per target than DAGCON_MAX_COVERAGE */
+    DAGCON_ERR_UNSUPPORTED = -5,    /* more alignments per target than DAGCON_MAX_COVERAGE, a target too
+                                       large for 25-bit vertex ids, an undefined bit in dagcon_opts.flags */
     DAGCON_ERR_WORKSPACE = -6,      /* device workspace could not be grown */
     DAGCON_ERR_INTERNAL = -7,       /* device-side invariant violated */
     DAGCON_ERR_STATE = -8           /* call sequence error (run before upload, ...) */
@@ -57,6 +58,9 @@ typedef enum dagcon_status {
 #define DAGCON_FLAG_STOP_AFTER_MERGE 4u /* debug: stop after mergeNodes */
 #define DAGCON_FLAG_DEBUG_RESWEEP 16u   /* debug: treat the segmented bestPath sweep as inexact, so that
                                            every target takes the one-piece re-sweep (tests only) */
+#define DAGCON_FLAGS_ALL (DAGCON_FLAG_RAW_ALIGNMENTS | DAGCON_FLAG_STOP_AFTER_BUILD | \
+                          DAGCON_FLAG_STOP_AFTER_MERGE | DAGCON_FLAG_DEBUG_RESWEEP)
+                                        /* dagcon_create refuses any other bit (DAGCON_ERR_UNSUPPORTED) */
 
 /* Mirrors ProgramOpts (src/cpp/ProgramOpts.hpp:8-36) for this path. */
 typedef struct dagcon_opts {
@@ -117,6 +121,14 @@ typedef struct dagcon_results {
     const uint32_t *seq_len;     /* [n_segments] */
     const char *seq_blob;
     uint64_t seq_bytes;
+    /* ABI 2.  A failure is confined to its target, as in the reference, where an assert or the
+     * undefined behaviour behind it hits one worker's one target (AlnGraphBoost.cpp:71-72):
+     * target_status[t] is DAGCON_OK or the dagcon_status that target alone failed with
+     * (DAGCON_ERR_NONCONFORMING, DAGCON_ERR_UNSUPPORTED: too large, DAGCON_ERR_INTERNAL); a failed
+     * target has no segments, every other target of the batch is complete and exact.  The call
+     * that filled the struct still returns DAGCON_OK; dagcon_last_error describes the first failure. */
+    const int32_t *target_status; /* [n_targets] */
+    uint32_t n_failed;            /* targets whose status is not DAGCON_OK */
 } dagcon_results;
 
 /* Per-stage device time of the last dagcon_run, from HIP events on the
@@ -155,6 +167,14 @@ int dagcon_run(dagcon_ctx *ctx);                               /* enqueue all ke
 int dagcon_sync(dagcon_ctx *ctx);                              /* wait for the stream */
 int dagcon_fetch(dagcon_ctx *ctx, dagcon_results *results);    /* sync + status check + D2H */
 int dagcon_get_timings(dagcon_ctx *ctx, dagcon_timings *out);  /* after dagcon_sync / dagcon_fetch */
+
+/*
+ * Page-locked host memory for the input blobs (qstr / tstr / backbone): a caller that parses
+ * alignment records straight into such a buffer gets its dagcon_upload at link speed instead of
+ * through the driver's staging copies.  Optional: any host memory is accepted by dagcon_upload.
+ */
+int  dagcon_host_alloc(dagcon_ctx *ctx, size_t bytes, void **out);
+void dagcon_host_free(dagcon_ctx *ctx, void *p);
 
 /*
  * Unit-level entry point for stage a1 alone: normalizeGaps (Alignment.cpp:

@@ -29,8 +29,9 @@ EXPORTS = [
     "dagcon_abi_version", "dagcon_default_opts", "dagcon_create", "dagcon_destroy",
     "dagcon_last_error", "dagcon_consensus", "dagcon_upload", "dagcon_run", "dagcon_sync",
     "dagcon_fetch", "dagcon_get_timings", "dagcon_normalize", "dagcon_debug_graph",
-    "dagcon_debug_counters",
+    "dagcon_debug_counters", "dagcon_host_alloc", "dagcon_host_free",
 ]
+ABI_VERSION = 2
 
 
 class DagconError(RuntimeError):
@@ -57,7 +58,8 @@ class Results(C.Structure):
                 ("seg_begin", C.POINTER(C.c_uint64)), ("range0", C.POINTER(C.c_int32)),
                 ("range1", C.POINTER(C.c_int32)), ("seq_off", C.POINTER(C.c_uint64)),
                 ("seq_len", C.POINTER(C.c_uint32)), ("seq_blob", C.c_void_p),
-                ("seq_bytes", C.c_uint64)]
+                ("seq_bytes", C.c_uint64), ("target_status", C.POINTER(C.c_int32)),
+                ("n_failed", C.c_uint32)]
 
 
 class Timings(C.Structure):
@@ -107,6 +109,9 @@ def load() -> C.CDLL:
     L.dagcon_normalize.argtypes = [vp, C.c_uint32, vp, vp, vp, vp, vp, C.c_uint64, C.c_uint32,
                                    C.c_uint32, vp, vp, vp, vp, vp]
     L.dagcon_debug_graph.argtypes = [vp, C.c_uint32, C.POINTER(GraphDump)]
+    L.dagcon_host_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
+    L.dagcon_host_free.argtypes = [vp, vp]
+    L.dagcon_host_free.restype = None
     _LIB = L
     return L
 
@@ -201,11 +206,33 @@ class Context:
         if rc != DAGCON_OK:
             raise DagconError(rc, "dagcon_create failed (is a gfx950 GPU visible?)")
         self._keep = None
+        self._pinned = []
+        self.target_status = None      # per-target dagcon_status of the last fetch (ABI 2)
 
     def close(self):
         if getattr(self, "h", None) and self.h.value:
+            for p in self._pinned:
+                self.L.dagcon_host_free(self.h, p)
+            self._pinned = []
             self.L.dagcon_destroy(self.h)
             self.h = C.c_void_p()
+
+    def host_array(self, nbytes):
+        """uint8 numpy array over page-locked host memory (dagcon_host_alloc); freed by close()."""
+        p = C.c_void_p()
+        self._chk(self.L.dagcon_host_alloc(self.h, max(int(nbytes), 1), C.byref(p)))
+        self._pinned.append(p)
+        return np.ctypeslib.as_array((C.c_uint8 * max(int(nbytes), 1)).from_address(p.value))[:int(nbytes)]
+
+    def pin_batch(self, batch: "HostBatch") -> "HostBatch":
+        """A copy of the batch whose string blobs live in page-locked memory."""
+        q = self.host_array(batch.qstr.size); q[:] = batch.qstr
+        t = self.host_array(batch.tstr.size); t[:] = batch.tstr
+        bb = None
+        if batch.backbone is not None:
+            bb = self.host_array(batch.backbone.size); bb[:] = batch.backbone
+        return HostBatch(batch.tlen, batch.aln_begin, batch.aln_start, batch.aln_off, batch.aln_len, q, t,
+                         bb, batch.backbone_off, batch.ids)
 
     def __del__(self):
         try:
@@ -228,9 +255,19 @@ class Context:
     def sync(self):
         self._chk(self.L.dagcon_sync(self.h))
 
-    def fetch(self):
+    def _status(self, r, strict):
+        """ABI 2: a failure is confined to its target.  strict (the default) raises for the first failed
+        target, as a caller that cannot use a partial batch wants; strict=False returns the batch with
+        [] for the failed targets and leaves their codes in self.target_status."""
+        self.target_status = np.ctypeslib.as_array(r.target_status, shape=(r.n_targets,)).copy() if r.n_targets else np.zeros(0, np.int32)
+        if strict and r.n_failed:
+            t = int(np.flatnonzero(self.target_status)[0])
+            raise DagconError(int(self.target_status[t]), (self.L.dagcon_last_error(self.h) or b"").decode())
+
+    def fetch(self, strict=True):
         r = Results()
         self._chk(self.L.dagcon_fetch(self.h, C.byref(r)))
+        self._status(r, strict)
         return _results_to_py(r)
 
     def fetch_raw(self):
@@ -239,16 +276,18 @@ class Context:
         caller can start the next run first and convert (results_to_py) meanwhile."""
         r = Results()
         self._chk(self.L.dagcon_fetch(self.h, C.byref(r)))
+        self._status(r, True)
         return r
 
     results_to_py = staticmethod(lambda r: _results_to_py(r))
 
-    def consensus(self, batch: HostBatch):
+    def consensus(self, batch: HostBatch, strict=True):
         """Per target: [(range0, range1, seq_bytes)]."""
         self._keep = batch
         b = batch.c_struct()
         r = Results()
         self._chk(self.L.dagcon_consensus(self.h, C.byref(b), C.byref(r)))
+        self._status(r, strict)
         return _results_to_py(r)
 
     def timings(self) -> dict:

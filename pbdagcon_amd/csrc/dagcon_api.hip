@@ -54,7 +54,7 @@ struct Ctx {
     uint64_t tmp_main = 0, tmp_cap = 0;
 
     // device buffers
-    DevBuf d_q, d_t, d_aln_off, d_aln_len, d_aln_start, d_aln_tgt, d_tlen, d_aln_begin, d_tactive,
+    DevBuf d_tfail, d_q, d_t, d_aln_off, d_aln_len, d_aln_start, d_aln_tgt, d_tlen, d_aln_begin, d_tactive,
         d_bb, d_bb_off, d_mat_base, d_bbv_base, d_matc_base, d_matc_stride;
     DevBuf d_nmis, d_norm_off, d_n_lo, d_n_hi, d_n_start, d_n_ins, d_n_del, d_norm;
     DevBuf d_ch_aln, d_ch_base, d_ch_k0, d_ch_next, d_ch_w, d_ch_tb, d_ch_flag, d_ch_src, d_ch_out, d_ch_adv,
@@ -62,11 +62,12 @@ struct Ctx {
     DevBuf d_node_base, d_n_nodes, d_pool_base, d_pool_size, d_pool_top, d_t_nins;
     DevBuf d_matA, d_matD, d_matC, d_cov, d_gcount, d_gbase, d_bid;
     DevBuf d_nodes, d_best, d_queue, d_score, d_cns_tmp, d_bp_tt;
-    DevBuf d_pool, d_stk, d_cuts, d_cuts_bp, d_bp_stat, d_bp_len;
+    DevBuf d_pool, d_stk, d_cuts, d_cuts_bp, d_bp_stat, d_bp_len, d_cuts_ln, d_stk_ln;
     DevBuf d_cns, d_cns_off, d_cns_len, d_seg_first, d_n_seg, d_seg_r0, d_seg_r1, d_st;
 
     uint64_t norm_cap = 0, node_cap = 0, pool_cap = 0, cns_cap = 0, seg_cap = 0;
     uint32_t stk_words = 4096, growth_pct = 100, seg_max = 8, bp_max = 16, seg_env = 0;    // (scratch per target and segment: grown x4 and re-run on DG_E_STACK)
+    uint32_t ln_max = 0, ln_space = 16, stk_ln_words = 0;   // lane-per-stretch merge (0 slots: off)
     uint64_t expected_workers = 0;                  // merge workers the batch will probably run (prefetch on / off)
 
     DgStatus h_st;
@@ -75,7 +76,8 @@ struct Ctx {
     // results (host)
     std::vector<uint64_t> r_seg_begin, r_seq_off, r_cns_off, r_seg_first;
     std::vector<int32_t> r_range0, r_range1, r_tmp0, r_tmp1;
-    std::vector<uint32_t> r_seq_len, r_cns_len, r_n_seg;
+    std::vector<uint32_t> r_seq_len, r_cns_len, r_n_seg, r_tfail;
+    std::vector<int32_t> r_status;
     char *r_blob = nullptr;             // page-locked: the consensus blob comes back at PCIe speed
     size_t r_blob_cap = 0;
 
@@ -149,6 +151,10 @@ int ensure_arenas(Ctx *c) {
     ENSURE(c, c->d_cuts_bp, (uint64_t)c->T * (c->bp_max + 2) * 4);
     ENSURE(c, c->d_bp_stat, (uint64_t)c->T * c->bp_max * 8);
     ENSURE(c, c->d_bp_len, (uint64_t)c->T * c->bp_max * 4);
+    if (c->ln_max) {
+        ENSURE(c, c->d_cuts_ln, (uint64_t)c->T * (c->ln_max + 2) * 4);
+        ENSURE(c, c->d_stk_ln, (uint64_t)c->T * ((c->ln_max + 63) / 64) * 64 * c->stk_ln_words * 4);
+    }
     ENSURE(c, c->d_cns, c->cns_cap);
     ENSURE(c, c->d_seg_r0, c->seg_cap * 4);
     ENSURE(c, c->d_seg_r1, c->seg_cap * 4);
@@ -164,7 +170,7 @@ void fill_params(Ctx *c, DgParams &p) {
     p.aln_tgt = (const uint32_t *)c->d_aln_tgt.p;
     p.tlen = (const uint32_t *)c->d_tlen.p;
     p.aln_begin = (const uint64_t *)c->d_aln_begin.p;
-    p.tactive = (const uint8_t *)c->d_tactive.p;
+    p.tactive = (const uint8_t *)c->d_tactive.p; p.tfail = (uint32_t *)c->d_tfail.p;
     p.bb = c->have_bb ? (const uint8_t *)c->d_bb.p : nullptr;
     p.bb_off = (const uint64_t *)c->d_bb_off.p;
     p.mat_base = (const uint64_t *)c->d_mat_base.p;
@@ -204,6 +210,8 @@ void fill_params(Ctx *c, DgParams &p) {
     // workers hide each other's latency and it only takes issue slots from them
     { const char *e = getenv("DAGCON_PF_AHEAD"); p.pf_ahead = e ? (uint32_t)atoi(e) : (c->expected_workers >= 4096 ? 0u : 48u); }
     p.seg_max = c->seg_max; p.seg_min = c->opts.min_segment_len ? c->opts.min_segment_len : 768u; p.cuts = (uint32_t *)c->d_cuts.p; p.bp_max = c->bp_max; p.cuts_bp = (uint32_t *)c->d_cuts_bp.p; p.bp_stat = (float *)c->d_bp_stat.p; p.bp_len = (uint32_t *)c->d_bp_len.p;
+    p.ln_max = c->ln_max; p.ln_space = c->ln_space; p.cuts_ln = (uint32_t *)c->d_cuts_ln.p;
+    p.stk_ln = (int32_t *)c->d_stk_ln.p; p.stk_ln_words = c->stk_ln_words;
     p.cns = (uint8_t *)c->d_cns.p; p.cns_cap = c->cns_cap;
     p.cns_off = (uint64_t *)c->d_cns_off.p; p.cns_len = (uint32_t *)c->d_cns_len.p;
     p.seg_first = (uint64_t *)c->d_seg_first.p; p.n_seg = (uint32_t *)c->d_n_seg.p;
@@ -231,6 +239,7 @@ int launch_all(Ctx *c) {
     fill_params(c, p);
     hipStream_t s = c->stream;
     HIPCHK(c, hipMemsetAsync(c->d_st.p, 0, sizeof(DgStatus), s));
+    HIPCHK(c, hipMemsetAsync(c->d_tfail.p, 0, (size_t)c->T * 4 + 4, s));
     HIPCHK(c, hipMemsetAsync(c->d_cns_len.p, 0, (size_t)c->T * 4, s));
     HIPCHK(c, hipMemsetAsync(c->d_n_seg.p, 0, (size_t)c->T * 4, s));
     if (c->matc_cells) HIPCHK(c, hipMemsetAsync(c->d_matC.p, 0, c->matc_cells * 4, s));
@@ -254,7 +263,10 @@ int launch_all(Ctx *c) {
     HIPCHK(c, hipEventRecord(c->ev[2], s));
     if (c->T > 0 && !(c->opts.flags & DAGCON_FLAG_STOP_AFTER_BUILD)) {
         hipLaunchKernelGGL(k_cuts, dim3(c->T), dim3(64), 0, s, p);
-        if (p.pf_ahead) hipLaunchKernelGGL(k_merge<true>, dim3(c->T * c->seg_max), dim3(128), 0, s, p);
+        if (c->ln_max) {
+            hipLaunchKernelGGL(k_cuts_fine, dim3(c->T), dim3(256), 0, s, p);
+            hipLaunchKernelGGL(k_merge_lanes, dim3(c->T * ((c->ln_max + 63) / 64)), dim3(64), 0, s, p);
+        } else if (p.pf_ahead) hipLaunchKernelGGL(k_merge<true>, dim3(c->T * c->seg_max), dim3(128), 0, s, p);
         else hipLaunchKernelGGL(k_merge<false>, dim3(c->T * c->seg_max), dim3(64), 0, s, p);
     }
     HIPCHK(c, hipEventRecord(c->ev[3], s));
@@ -292,6 +304,12 @@ int dagcon_create(const dagcon_opts *opts, dagcon_ctx **out) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return DAGCON_ERR_NO_DEVICE;
     if (opts->device < 0 || opts->device >= ndev) return DAGCON_ERR_NO_DEVICE;
+    if (opts->flags & ~DAGCON_FLAGS_ALL) return DAGCON_ERR_UNSUPPORTED;   // (internal bits start at 8: never from outside)
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, opts->device) != hipSuccess || strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+            return DAGCON_ERR_NO_DEVICE;                      // the code object is gfx950 only
+    }
     Ctx *c = new Ctx();
     c->opts = *opts;
     c->device = opts->device;
@@ -323,12 +341,12 @@ void dagcon_destroy(dagcon_ctx *ctx) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->r_blob) (void)hipHostFree(c->r_blob);
     DevBuf *all[] = {&c->d_q, &c->d_t, &c->d_aln_off, &c->d_aln_len, &c->d_aln_start, &c->d_aln_tgt,
-                     &c->d_tlen, &c->d_aln_begin, &c->d_tactive, &c->d_bb, &c->d_bb_off, &c->d_mat_base, &c->d_matc_base, &c->d_matc_stride,
+                     &c->d_tlen, &c->d_aln_begin, &c->d_tactive, &c->d_tfail, &c->d_bb, &c->d_bb_off, &c->d_mat_base, &c->d_matc_base, &c->d_matc_stride,
                      &c->d_bbv_base, &c->d_nmis, &c->d_norm_off, &c->d_n_lo, &c->d_n_hi, &c->d_n_start, &c->d_ch_aln, &c->d_ch_base, &c->d_ch_k0, &c->d_ch_next, &c->d_ch_w, &c->d_ch_tb, &c->d_ch_flag, &c->d_ch_src, &c->d_ch_out, &c->d_ch_adv, &c->d_n_lb, &c->d_norm_tmp, &c->d_ckpt, &c->d_ck_base,
                      &c->d_n_ins, &c->d_n_del, &c->d_norm, &c->d_node_base, &c->d_n_nodes,
                      &c->d_pool_base, &c->d_pool_size, &c->d_pool_top, &c->d_t_nins, &c->d_matA, &c->d_matD,
                      &c->d_matC, &c->d_cov, &c->d_gcount, &c->d_gbase, &c->d_bid, &c->d_nodes,
-                     &c->d_best, &c->d_queue, &c->d_score, &c->d_cns_tmp, &c->d_bp_tt, &c->d_pool, &c->d_stk, &c->d_cuts, &c->d_cuts_bp, &c->d_bp_stat, &c->d_bp_len, &c->d_cns,
+                     &c->d_best, &c->d_queue, &c->d_score, &c->d_cns_tmp, &c->d_bp_tt, &c->d_pool, &c->d_stk, &c->d_cuts, &c->d_cuts_bp, &c->d_bp_stat, &c->d_bp_len, &c->d_cuts_ln, &c->d_stk_ln, &c->d_cns,
                      &c->d_cns_off, &c->d_cns_len, &c->d_seg_first, &c->d_n_seg, &c->d_seg_r0, &c->d_seg_r1,
                      &c->d_st};
     for (DevBuf *b : all) free_buf(*b);
@@ -359,7 +377,16 @@ int dagcon_upload(dagcon_ctx *ctx, const dagcon_batch *b) {
     // sequential sweep when that is asked for)
     c->bp_max = c->seg_max == 1 ? 1u : std::min(64u, 3u * c->seg_max);
     if (const char *e = getenv("DAGCON_BP_SEGS")) { const int v = atoi(e); if (v >= 1 && v <= 64) c->bp_max = (uint32_t)v; }
+    // scratch per (target, piece): 4096 words where that is cheap, less for batches of very many
+    // targets (2 GB in all at most; a piece that needs more raises DG_E_STACK: grown x4, re-run)
+    {
+        const uint64_t pieces = std::max<uint64_t>(1, (uint64_t)T * c->bp_max);
+        const uint32_t fit = (uint32_t)std::min<uint64_t>(4096, (512ull << 20) / pieces);
+        const uint32_t base = std::max(256u, fit);
+        if (c->stk_words < base || (uint64_t)c->stk_words * pieces > (1024ull << 20)) c->stk_words = base;
+    }
     c->h_tlen.assign(b->tlen, b->tlen + T);
+    c->ln_max = 0;
     c->h_aln_begin.assign(T + 1, 0);
     c->h_tactive.assign(T, 0);
     c->h_mat_base.assign(T, 0);
@@ -383,7 +410,7 @@ int dagcon_upload(dagcon_ctx *ctx, const dagcon_batch *b) {
         c->h_tactive[t] = 1;
         for (uint64_t a = ab; a < ae; a++) {
             const uint32_t len = b->aln_len[a];
-            if (b->aln_off[a] + len > b->blob_bytes)
+            if (b->aln_off[a] > b->blob_bytes || len > b->blob_bytes - b->aln_off[a])
                 return fail(c, DAGCON_ERR_INVALID_ARG, "alignment %llu runs past the blob", (unsigned long long)a);
             if (len < c->opts.min_len) continue;       // main.cpp:132
             c->h_aln_len.push_back(len);
@@ -411,6 +438,13 @@ int dagcon_upload(dagcon_ctx *ctx, const dagcon_batch *b) {
         if (c->have_bb) {
             c->h_bb_off[t] = b->backbone_off[t];
             bb_bytes = std::max<uint64_t>(bb_bytes, b->backbone_off[t] + b->tlen[t]);
+        }
+    }
+    if (const char *e = getenv("DAGCON_LANE_MERGE")) {
+        if (atoi(e) > 0) {
+            if (const char *e2 = getenv("DAGCON_LN_SPACE")) { const int v = atoi(e2); if (v >= 1) c->ln_space = (uint32_t)v; }
+            c->ln_max = std::max(1u, std::min(8192u, c->max_tlen / c->ln_space + 1u));
+            c->stk_ln_words = std::max(c->stk_ln_words, std::max(256u, 3u * (2u * (c->max_k + 2u) + 3u)));
         }
     }
     c->h_aln_begin[T] = c->h_aln_len.size();
@@ -492,7 +526,7 @@ int dagcon_upload(dagcon_ctx *ctx, const dagcon_batch *b) {
     }
     ENSURE(c, c->d_node_base, (size_t)T * 8); ENSURE(c, c->d_n_nodes, T4);
     ENSURE(c, c->d_pool_base, (size_t)T * 8); ENSURE(c, c->d_pool_size, T4); ENSURE(c, c->d_pool_top, T4);
-    ENSURE(c, c->d_t_nins, T4);
+    ENSURE(c, c->d_t_nins, T4); ENSURE(c, c->d_tfail, T4 + 4);
     ENSURE(c, c->d_matA, c->mat_cells * 4); ENSURE(c, c->d_matD, c->mat_cells * 4);
     ENSURE(c, c->d_matC, c->matc_cells * 4 + 256);
     ENSURE(c, c->d_cov, c->sum_bb * 4); ENSURE(c, c->d_gcount, c->sum_bb * 4);
@@ -548,20 +582,14 @@ int dagcon_fetch(dagcon_ctx *ctx, dagcon_results *res) {
         if ((r = read_status(c))) return r;
         const uint32_t f = c->h_st.err_flags;
         if (f == 0) break;
-        if (f & DG_E_BADCHAR)
-            return fail(c, DAGCON_ERR_NONCONFORMING, "alignment %u holds a byte outside printable ASCII", c->h_st.bad_aln);
-        if (f & DG_E_NONCONF)
-            return fail(c, DAGCON_ERR_NONCONFORMING,
-                        "alignment %u (after the min_len filter) leaves the backbone: start < 1 or target bases past tlen",
-                        c->h_st.bad_aln);
-        if (f & DG_E_INTERNAL)
-            return fail(c, DAGCON_ERR_INTERNAL, "device invariant violated in target %u", c->h_st.bad_target);
+        if (f & DG_E_TARGET_MASK)       // (target-level failures never set the batch flag: see DgParams::tfail)
+            return fail(c, DAGCON_ERR_INTERNAL, "unexpected batch-level flag 0x%x", f);
         if (attempt >= 6) return fail(c, DAGCON_ERR_WORKSPACE, "workspace still too small after %d re-runs (flags 0x%x)", attempt, f);
         if (f & DG_E_NORM_OVF) c->norm_cap = c->h_st.norm_top + 1024;
         if (f & DG_E_NODE_OVF) c->node_cap = c->h_st.node_need + 1024;
         if (f & DG_E_POOL_OVF) c->pool_cap = c->h_st.pool_need + 1024;
         if (f & DG_E_POOL_TGT) c->growth_pct *= 3;
-        if (f & DG_E_STACK) c->stk_words *= 4;
+        if (f & DG_E_STACK) { c->stk_words *= 4; c->stk_ln_words *= 4; }
         if (f & DG_E_OUT_OVF) {
             c->cns_cap = std::max<uint64_t>(c->cns_cap, c->h_st.cns_top + 1024);
             c->seg_cap = std::max<uint64_t>(c->seg_cap, c->h_st.seg_top + 1024);
@@ -578,6 +606,24 @@ int dagcon_fetch(dagcon_ctx *ctx, dagcon_results *res) {
     HIPCHK(c, hipEventElapsedTime(&ms, c->ev[3], c->ev[4])); c->tm.ms_bestpath = ms;
 
     const uint32_t T = c->T;
+    // per-target outcome (ABI 2): a failure is confined to its target
+    c->r_tfail.assign(T, 0); c->r_status.assign(T, DAGCON_OK);
+    if (T) HIPCHK(c, hipMemcpy(c->r_tfail.data(), c->d_tfail.p, (size_t)T * 4, hipMemcpyDeviceToHost));
+    uint32_t n_failed = 0;
+    c->err.clear();
+    for (uint32_t t = 0; t < T; t++) {
+        const uint32_t f = c->r_tfail[t];
+        if (!f) continue;
+        const int code = (f & (DG_E_BADCHAR | DG_E_NONCONF)) ? DAGCON_ERR_NONCONFORMING
+                       : (f & DG_E_TOO_BIG) ? DAGCON_ERR_UNSUPPORTED : DAGCON_ERR_INTERNAL;
+        c->r_status[t] = code;
+        if (!n_failed++) {
+            if (f & DG_E_BADCHAR) fail(c, code, "target %u: an alignment holds a byte outside printable ASCII", t);
+            else if (f & DG_E_NONCONF) fail(c, code, "target %u: an alignment (after the min_len filter) leaves the backbone: start < 1 or target bases past tlen", t);
+            else if (f & DG_E_TOO_BIG) fail(c, code, "target %u too large (more than 2^25 - 3 vertices or 2^30 pool words)", t);
+            else fail(c, code, "device invariant violated in target %u", t);
+        }
+    }
     const uint64_t nseg = c->h_st.seg_top, nb = c->h_st.cns_top;
     c->r_cns_off.assign(T, 0); c->r_cns_len.assign(T, 0); c->r_seg_first.assign(T, 0); c->r_n_seg.assign(T, 0);
     c->r_tmp0.assign(nseg, 0); c->r_tmp1.assign(nseg, 0);
@@ -606,7 +652,7 @@ int dagcon_fetch(dagcon_ctx *ctx, dagcon_results *res) {
     uint64_t bases = 0;
     for (uint32_t t = 0; t < T; t++) {
         c->r_seg_begin[t] = c->r_range0.size();
-        if (!full || !c->h_tactive[t]) continue;
+        if (!full || !c->h_tactive[t] || c->r_tfail[t]) continue;
         for (uint32_t i = 0; i < c->r_n_seg[t]; i++) {
             const uint64_t s = c->r_seg_first[t] + i;
             const int32_t r0 = c->r_tmp0[s], r1 = c->r_tmp1[s];
@@ -629,6 +675,7 @@ int dagcon_fetch(dagcon_ctx *ctx, dagcon_results *res) {
     res->range0 = c->r_range0.data(); res->range1 = c->r_range1.data();
     res->seq_off = c->r_seq_off.data(); res->seq_len = c->r_seq_len.data();
     res->seq_blob = c->r_blob; res->seq_bytes = nb;
+    res->target_status = c->r_status.data(); res->n_failed = n_failed;
     c->fetched = true;
     return DAGCON_OK;
 }
@@ -691,6 +738,7 @@ static int normalize_impl(Ctx *c, dagcon_ctx *ctx, uint32_t n, const uint32_t *a
         fill_params(c, p);
         p.flags |= DG_F_A1_ONLY;
         HIPCHK(c, hipMemsetAsync(c->d_st.p, 0, sizeof(DgStatus), c->stream));
+        HIPCHK(c, hipMemsetAsync(c->d_tfail.p, 0, (size_t)c->T * 4 + 4, c->stream));
         launch_normalize(c, p);
         HIPCHK(c, hipGetLastError());
         if ((r = read_status(c))) return r;
@@ -745,6 +793,21 @@ int dagcon_normalize(dagcon_ctx *ctx, uint32_t n, const uint32_t *aln_start, con
     c->opts = saved;
     c->uploaded = false; c->ran = false;
     return r;
+}
+
+int dagcon_host_alloc(dagcon_ctx *ctx, size_t bytes, void **out) {
+    if (!ctx || !out) return DAGCON_ERR_INVALID_ARG;
+    Ctx *c = reinterpret_cast<Ctx *>(ctx);
+    *out = nullptr;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
+    return DAGCON_OK;
+}
+
+void dagcon_host_free(dagcon_ctx *ctx, void *p) {
+    if (!ctx || !p) return;
+    (void)hipSetDevice(reinterpret_cast<Ctx *>(ctx)->device);
+    (void)hipHostFree(p);
 }
 
 int dagcon_debug_graph(dagcon_ctx *ctx, uint32_t target, dagcon_graph_dump *out) {

@@ -36,6 +36,10 @@
 #define DG_E_OUT_OVF     0x100u  // output arena too small
 #define DG_E_TOO_BIG     0x200u  // a target has more than 2^25-2 vertices
 
+// failures of one target (its input, or an invariant of its graph): recorded in DgParams::tfail,
+// the batch goes on; everything else is a capacity problem of the whole batch (grow and re-run)
+#define DG_E_TARGET_MASK (DG_E_BADCHAR | DG_E_NONCONF | DG_E_INTERNAL | DG_E_TOO_BIG)
+
 struct DgStatus {
     uint32_t err_flags;
     uint32_t bad_aln;
@@ -85,6 +89,8 @@ struct DgParams {
     const uint32_t *tlen;
     const uint64_t *aln_begin;     // [T+1], indices into the (filtered) alignment arrays
     const uint8_t *tactive;        // [T] 1 = build a graph (main.cpp:66-72,118)
+    uint32_t *tfail;               // [T] DG_E_* bits of a failure confined to the target (bad input, broken
+                                   // invariant): later kernels skip it, the other targets of the batch complete
     const uint8_t *bb;             // optional backbone blob
     const uint64_t *bb_off;
     const uint64_t *mat_base;      // [T] offset into matA/matD/matC: (tlen+2) * K cells
@@ -155,6 +161,12 @@ struct DgParams {
     uint32_t *cuts_bp;             //   its waves are light), [T][bp_max + 2] like cuts
     float *bp_stat;                // [T][seg_max][2]: largest |score| of the segment, score of its first vertex
     uint32_t *bp_len;              // [T][seg_max]: vertices of the best path inside the segment (enter / exit excluded)
+    // ---- lane-per-stretch merge (k_cuts_fine, k_merge_lanes) ----
+    uint32_t ln_max;               // slots per target (0: the lane kernels are not used)
+    uint32_t ln_space;             // backbone positions per slot
+    uint32_t *cuts_ln;             // [T][ln_max + 2]: slots, first vertex of each slot (DG_NOCUT: none)
+    int32_t *stk_ln;               // per-lane scratch, stk_ln_words each
+    uint32_t stk_ln_words;
     // ---- outputs ----
     uint8_t *cns;
     uint64_t cns_cap;

@@ -40,6 +40,8 @@ namespace {
 struct Opts {
     unsigned threads = 4, min_cov = 6, min_len = 500, trim = 50;
     bool align = false, verbose = false, dump = false;
+    std::vector<int> devices{0};       // --devices: one consensus worker (thread + context) per GPU
+    int pinned = -1;                   // --pinned 0|1: page-locked blobs (-1: when the input is several batches long)
     size_t batch_targets = 256;        // small enough that parsing and the GPU overlap on mid-size inputs
     size_t batch_bytes = 1ull << 30;
     size_t slab_bytes = 0;             // test hook: text indexed per round (0 = automatic)
@@ -57,6 +59,8 @@ void usage(FILE *f) {
             "  -t, --trim          trim alignments on either side (default 50)\n"
             "  -a, --align         not available in this build (needs blasr_libcpp)\n"
             "  -v, --verbose       per-target progress on stderr\n"
+            "  --devices LIST      GPUs to use, e.g. 0,1,2,3 (default 0): one consensus worker per GPU, batches of\n"
+            "                      targets dealt round-robin, records still printed in input order\n"
             "  <input>             BLASR -m 5 file sorted by target, or - for stdin\n"
             "  version 0.3 (dagcon-mi355x)\n");
 }
@@ -86,6 +90,22 @@ int parse_args(int argc, char **argv, Opts &o) {
         else if (a == "-v" || a == "--verbose") o.verbose = true;
         else if (a == "--dump-parsed") o.dump = true;            // test hook: parser only, no GPU
         else if (a == "--slab-bytes") { unsigned v = 0; if (!need(&v)) return 2; o.slab_bytes = v; }   // test hook
+        else if (a == "--batch-targets") { unsigned v = 0; if (!need(&v) || !v) return 2; o.batch_targets = v; }
+        else if (a == "--pinned") { unsigned v = 0; if (!need(&v)) return 2; o.pinned = v ? 1 : 0; }
+        else if (a == "--devices") {
+            if (i + 1 >= argc) { fprintf(stderr, "PARSE ERROR: --devices needs a list such as 0,1,2\n"); return 2; }
+            o.devices.clear();
+            const char *p = argv[++i];
+            while (*p) {
+                char *e = nullptr;
+                const long v = strtol(p, &e, 10);
+                if (e == p || v < 0 || v > 1023) { fprintf(stderr, "PARSE ERROR: bad --devices list\n"); return 2; }
+                o.devices.push_back((int)v);
+                p = *e == ',' ? e + 1 : e;
+                if (*e && *e != ',') { fprintf(stderr, "PARSE ERROR: bad --devices list\n"); return 2; }
+            }
+            if (o.devices.empty()) { fprintf(stderr, "PARSE ERROR: --devices list is empty\n"); return 2; }
+        }
         else if (a == "-h" || a == "--help") { usage(stdout); exit(0); }
         else if (a == "--version") { printf("pbdagcon  version: 0.3\n"); exit(0); }
         else if (a == "-" || a[0] != '-') {
@@ -121,14 +141,43 @@ uint32_t tok_u32(const char *s, size_t n) {
     return neg ? (uint32_t)(0u - (uint32_t)v) : (uint32_t)v;
 }
 
+// string blob of a batch: page-locked (dagcon_host_alloc) when a context offers it, else malloc
+struct Blob {
+    char *p = nullptr;
+    size_t cap = 0, n = 0;
+    dagcon_ctx *owner = nullptr;       // context the page-locked block came from (nullptr: malloc)
+    void release() {
+        if (p) { if (owner) dagcon_host_free(owner, p); else free(p); }
+        p = nullptr; cap = 0; owner = nullptr;
+    }
+    bool resize(size_t bytes, dagcon_ctx *pin) {
+        if (bytes > cap) {
+            release();
+            const size_t want = bytes + bytes / 8 + 4096;
+            void *q = nullptr;
+            if (pin && dagcon_host_alloc(pin, want, &q) == DAGCON_OK) { p = (char *)q; owner = pin; }
+            else { p = (char *)malloc(want); owner = nullptr; }
+            if (!p) return false;
+            cap = want;
+        }
+        n = bytes;
+        return true;
+    }
+    char *data() { return p; }
+    size_t size() const { return n; }
+};
+
 struct Batch {
     std::vector<std::string> ids;
     std::vector<uint32_t> tlen, start, len;
     std::vector<uint64_t> begin{0}, off;
-    std::string q, t;
-    void clear() { ids.clear(); tlen.clear(); start.clear(); len.clear(); begin.assign(1, 0); off.clear(); q.clear(); t.clear(); }
+    Blob q, t;
+    unsigned long long seq = 0;        // position in the input: records are printed in this order
+    std::string out;                   // the batch's FASTA records
+    void clear() { ids.clear(); tlen.clear(); start.clear(); len.clear(); begin.assign(1, 0); off.clear(); q.n = 0; t.n = 0; out.clear(); }
 };
 
+// one batch through the device; the records go to b.out (main.cpp:141-143), warnings to stderr
 int flush(dagcon_ctx *ctx, Batch &b, const Opts &o) {
     if (b.ids.empty()) return 0;
     if (b.begin.back() != b.start.size()) b.begin.push_back(b.start.size());
@@ -144,18 +193,26 @@ int flush(dagcon_ctx *ctx, Batch &b, const Opts &o) {
         fprintf(stderr, "pbdagcon: consensus failed (%d): %s\n", rc, dagcon_last_error(ctx));
         return 1;
     }
+    char head[64];
     for (uint32_t g = 0; g < r.n_targets; g++) {
         if (o.verbose)
             fprintf(stderr, "Consensus calling: %s Alignments: %llu\n", b.ids[g].c_str(),
                     (unsigned long long)(b.begin[g + 1] - b.begin[g]));
+        // a failure is confined to its target (the reference's assert hits one worker's one target,
+        // AlnGraphBoost.cpp:71-72): warn, go on with the rest
+        if (r.target_status[g] != DAGCON_OK)
+            fprintf(stderr, "pbdagcon: warning: target %s skipped (%s)\n", b.ids[g].c_str(),
+                    r.target_status[g] == DAGCON_ERR_NONCONFORMING ? "an alignment leaves the backbone or holds a non-printable byte"
+                    : r.target_status[g] == DAGCON_ERR_UNSUPPORTED ? "too large" : "internal error");
         for (uint64_t s = r.seg_begin[g]; s < r.seg_begin[g + 1]; s++) {
             // main.cpp:141-143  ">%s/%d_%d\n%s\n"
-            printf(">%s/%d_%d\n", b.ids[g].c_str(), r.range0[s], r.range1[s]);
-            fwrite(r.seq_blob + r.seq_off[s], 1, r.seq_len[s], stdout);
-            fputc('\n', stdout);
+            b.out += '>'; b.out += b.ids[g];
+            snprintf(head, sizeof head, "/%d_%d\n", r.range0[s], r.range1[s]);
+            b.out += head;
+            b.out.append(r.seq_blob + r.seq_off[s], r.seq_len[s]);
+            b.out += '\n';
         }
     }
-    b.clear();
     return 0;
 }
 
@@ -193,58 +250,100 @@ int main(int argc, char **argv) {
         close(fd);
     }
 
-    // ---- the consensus thread: owns the context, takes full batches in order ----
-    Batch bufs[2];
-    int fill = 0;                           // the batch the parser is filling
+    // ---- consensus workers: one thread + context per GPU (the reference starts its N consensus
+    // workers itself too, main.cpp:251-274); batches are taken in input order from one queue, their
+    // records are printed in input order by whoever completes the next one in line ----
+    const size_t ndev = o.devices.size();
+    const size_t nbuf = ndev + 1;                          // the parser fills one while the others are on GPUs
+    std::vector<Batch> bufs(nbuf);
     std::mutex mu;
     std::condition_variable cv;
-    int pending = -1;                       // batch handed over and not taken yet
-    bool busy = false, stop = false;
+    std::vector<Batch *> free_list, work;                   // work: FIFO
+    for (auto &x : bufs) free_list.push_back(&x);
+    std::vector<Batch *> done;                              // completed, waiting for their turn to print
+    unsigned long long next_seq = 0, print_seq = 0;
+    bool stop = false;
     int worker_status = 0;
-    std::thread worker;
+    dagcon_ctx *pin_ctx = nullptr;                          // first context up: page-locked blobs come from it
+    bool want_pin = o.pinned == 1 || (o.pinned < 0 && size > 2 * o.batch_bytes);
+    std::vector<std::thread> workers;
     if (!o.dump) {
-        worker = std::thread([&] {
+        for (size_t w = 0; w < ndev; w++) workers.emplace_back([&, w] {
             dagcon_ctx *ctx = nullptr;
             dagcon_opts dopt;
             dagcon_default_opts(&dopt);
             dopt.min_cov = o.min_cov; dopt.min_len = o.min_len; dopt.trim = o.trim;
             dopt.min_weight = (int32_t)o.min_cov;          // main.cpp:261,279 (quirk Q1)
+            dopt.device = o.devices[w];
             int rc = dagcon_create(&dopt, &ctx);
             if (rc != DAGCON_OK) {
-                fprintf(stderr, "pbdagcon: no usable MI355X (dagcon_create = %d); there is no CPU fallback\n", rc);
+                fprintf(stderr, "pbdagcon: no usable MI355X as device %d (dagcon_create = %d); there is no CPU fallback\n", o.devices[w], rc);
                 std::lock_guard<std::mutex> lk(mu);
                 worker_status = 1;
                 cv.notify_all();
                 return;
             }
+            { std::lock_guard<std::mutex> lk(mu); if (!pin_ctx) pin_ctx = ctx; }
             for (;;) {
-                int idx;
+                Batch *b = nullptr;
                 {
                     std::unique_lock<std::mutex> lk(mu);
-                    cv.wait(lk, [&] { return pending >= 0 || stop; });
-                    if (pending < 0) break;
-                    idx = pending; pending = -1; busy = true;
+                    cv.wait(lk, [&] { return !work.empty() || stop; });
+                    if (work.empty()) break;
+                    b = work.front(); work.erase(work.begin());
                 }
-                const int st = flush(ctx, bufs[idx], o);
+                const int st = flush(ctx, *b, o);
                 {
-                    std::lock_guard<std::mutex> lk(mu);
-                    busy = false;
+                    std::unique_lock<std::mutex> lk(mu);
                     if (st) worker_status = st;
+                    done.push_back(b);
+                    // print what is next in line (this batch and any that were waiting on it)
+                    for (bool again = true; again;) {
+                        again = false;
+                        for (size_t i = 0; i < done.size(); i++) {
+                            if (done[i]->seq != print_seq) continue;
+                            Batch *d = done[i];
+                            done.erase(done.begin() + i);
+                            fwrite(d->out.data(), 1, d->out.size(), stdout);
+                            d->clear();
+                            free_list.push_back(d);
+                            print_seq++;
+                            again = true;
+                            break;
+                        }
+                    }
                 }
                 cv.notify_all();
+            }
+            // (blobs that were page-locked through this context are released before it goes)
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                for (auto &x : bufs) { if (x.q.owner == ctx) x.q.release(); if (x.t.owner == ctx) x.t.release(); }
+                if (pin_ctx == ctx) pin_ctx = nullptr;
             }
             dagcon_destroy(ctx);
         });
     }
-    // hands the filled batch to the consensus thread (waits for the previous one), returns the other buffer
-    auto submit = [&]() -> int {
+    Batch *bp = nullptr;
+    // a free batch buffer for the parser (waits for a worker to finish one)
+    auto acquire = [&]() -> Batch * {
         std::unique_lock<std::mutex> lk(mu);
-        cv.wait(lk, [&] { return (pending < 0 && !busy) || worker_status; });
-        if (worker_status) return worker_status;
-        pending = fill;
-        fill ^= 1;
+        cv.wait(lk, [&] { return !free_list.empty() || worker_status; });
+        if (free_list.empty()) return nullptr;
+        Batch *b = free_list.back(); free_list.pop_back();
+        return b;
+    };
+    // hands the filled batch to the workers and takes the next free buffer
+    auto submit = [&]() -> int {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (worker_status) return worker_status;
+            bp->seq = next_seq++;
+            work.push_back(bp);
+        }
         cv.notify_all();
-        return 0;
+        bp = acquire();
+        return bp ? 0 : 1;
     };
 
     // ---- parse (Alignment.cpp:44-80) and group by target id (BlasrM5AlnProvider.cpp:34-55) ----
@@ -339,11 +438,13 @@ int main(int argc, char **argv) {
     };
     // copies the strings of records [r0, r1) into batch b, whose offsets are set already
     auto fill_strings = [&](Batch &b, size_t r0, size_t r1, size_t bytes) {
-        b.q.resize(bytes); b.t.resize(bytes);
+        dagcon_ctx *pin = nullptr;
+        if (want_pin) { std::lock_guard<std::mutex> lk(mu); pin = pin_ctx; }
+        if (!b.q.resize(bytes, pin) || !b.t.resize(bytes, pin)) { fprintf(stderr, "pbdagcon: out of memory\n"); exit(1); }
         auto work = [&](unsigned k) {
             for (size_t x = r0 + k; x < r1; x += nthr) {
                 const Rec &r = *recs[x];
-                char *dq = &b.q[b.off[x - r0]], *dt = &b.t[b.off[x - r0]];
+                char *dq = b.q.data() + b.off[x - r0], *dt = b.t.data() + b.off[x - r0];
                 if (r.strand == '-') {                            // Alignment.cpp:69-75: start is NOT flipped (Q6)
                     revcomp_into(dq, r.q, r.len);
                     revcomp_into(dt, r.t, r.len);
@@ -358,7 +459,9 @@ int main(int argc, char **argv) {
         work(0);
         for (auto &x : th) x.join();
     };
-    Batch *bp = &bufs[0];
+    bp = &bufs[0];
+    if (!o.dump) bp = acquire();
+    if (!bp) status = 1;
 #define b (*bp)
     while (status == 0 && !had_error && (slab_pos < size || !carry.empty())) {
         size_t s1 = std::min(size, slab_pos + slab_bytes);
@@ -397,7 +500,7 @@ int main(int argc, char **argv) {
                                    (int)r.namel, r.name, (int)r.len, b.q.data() + o0, (int)r.len, b.t.data() + o0);
                         }
                         b.clear();
-                    } else { status = submit(); bp = &bufs[fill]; }
+                    } else status = submit();
                 }
                 rb = x; bytes = 0;
                 if (last || status) break;
@@ -423,16 +526,17 @@ int main(int argc, char **argv) {
     if (had_error) status = 1;
 #undef b
     if (!o.dump) {
-        if (status == 0) status = submit();
         {
             std::unique_lock<std::mutex> lk(mu);
-            cv.wait(lk, [&] { return (pending < 0 && !busy) || worker_status; });
+            // every submitted batch printed (or a worker gave up)
+            cv.wait(lk, [&] { return print_seq == next_seq || worker_status; });
             stop = true;
             if (worker_status && !status) status = worker_status;
         }
         cv.notify_all();
-        worker.join();
+        for (auto &w : workers) w.join();
     }
+    for (auto &x : bufs) { x.q.release(); x.t.release(); }
     if (map) munmap(map, size);
     fflush(stdout);
     return status;

@@ -46,7 +46,7 @@
 #define DG_TT_TEN 1.0e30f
 __global__ __launch_bounds__(256) void k_bp_terms(DgParams p) {
     const uint32_t t = blockIdx.x;
-    if (dg_failed(p) || !p.tactive[t]) return;
+    if (dg_failed(p) || dg_tskip(p, t)) return;
     const uint64_t nb = p.node_base[t];
     const uint32_t N = p.n_nodes[t];
     const int32_t *cov = p.cov + p.bbv_base[t];
@@ -425,7 +425,7 @@ __device__ __forceinline__ void dg_bp_sweep(DgBpShared &S, const DgNode *nd, int
 // the arithmetic is exact, which k_bp_check verifies from the figures left here.
 __global__ __launch_bounds__(64) void k_bp_sweep(DgParams p) {
     const uint32_t t = blockIdx.x / p.bp_max, seg = blockIdx.x % p.bp_max;
-    if (dg_failed(p) || !p.tactive[t]) return;
+    if (dg_failed(p) || dg_tskip(p, t)) return;
     const uint32_t *crow = p.cuts_bp + (uint64_t)t * (p.bp_max + 2u);
     const uint32_t nseg = crow[0];
     if (seg >= nseg) return;
@@ -441,7 +441,7 @@ __global__ __launch_bounds__(64) void k_bp_sweep(DgParams p) {
                 c_top >= 0 ? c_top - 1 : N - 1, c_bot, c_top,
                 p.stk + (uint64_t)blockIdx.x * p.stk_words, (int)p.stk_words, lane, amax, bad, stuck);
     if (bad) {                                                    // STACK: the host grows the scratch and re-runs
-        if (lane == 0) { dg_fail(p, stuck ? DG_E_INTERNAL : DG_E_STACK); p.st->bad_target = t; }
+        if (lane == 0) { if (stuck) dg_fail_target(p, t, DG_E_INTERNAL); else { dg_fail(p, DG_E_STACK); p.st->bad_target = t; } }
         return;
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
@@ -452,7 +452,7 @@ __global__ __launch_bounds__(64) void k_bp_sweep(DgParams p) {
 // ---- exactness check of the segmented sweep, one wave per target -------------------
 __global__ __launch_bounds__(64) void k_bp_check(DgParams p) {
     const uint32_t t = blockIdx.x;
-    if (dg_failed(p) || !p.tactive[t]) return;
+    if (dg_failed(p) || dg_tskip(p, t)) return;
     const int lane = threadIdx.x;
     const uint64_t nb = p.node_base[t];
     // Every score is a multiple of 0.5, so fp32 is exact below 2^23.  A vertex of segment i has
@@ -483,7 +483,7 @@ __global__ __launch_bounds__(64) void k_bp_check(DgParams p) {
     bool bad = false, stuck = false;
     dg_bp_sweep(S, p.nodes + nb, p.best + nb, score, p.pool + p.pool_base[t], p.bp_tt + nb, N - 1, 0, -1,
                 p.stk + (uint64_t)t * p.bp_max * p.stk_words, (int)p.stk_words, lane, amax, bad, stuck);
-    if (bad && lane == 0) { dg_fail(p, stuck ? DG_E_INTERNAL : DG_E_STACK); p.st->bad_target = t; }
+    if (bad && lane == 0) { if (stuck) dg_fail_target(p, t, DG_E_INTERNAL); else { dg_fail(p, DG_E_STACK); p.st->bad_target = t; } }
 }
 
 // ---- the best-edge walk (:443-456), one wave per (target, segment) ----------------
@@ -492,7 +492,7 @@ __global__ __launch_bounds__(64) void k_bp_check(DgParams p) {
 // the scratch (ids of a segment are contiguous): the base, bit 7 = weight >= minWeight.
 __global__ __launch_bounds__(64) void k_bp_walk(DgParams p) {
     const uint32_t t = blockIdx.x / p.bp_max, seg = blockIdx.x % p.bp_max;
-    if (dg_failed(p) || !p.tactive[t]) return;
+    if (dg_failed(p) || dg_tskip(p, t)) return;
     const uint32_t *crow = p.cuts_bp + (uint64_t)t * (p.bp_max + 2u);
     const uint32_t nseg = crow[0];
     if (seg >= nseg) return;
@@ -547,7 +547,7 @@ __global__ __launch_bounds__(64) void k_bp_walk(DgParams p) {
     }
     if (lane < (idx & 63)) tmp[(idx & ~63) + lane] = W.wbuf[lane];     // the last, partial row
     if (lane == 0) {
-        if (bad) { dg_fail(p, DG_E_INTERNAL); p.st->bad_target = t; }
+        if (bad) dg_fail_target(p, t, DG_E_INTERNAL);
         p.bp_len[blockIdx.x] = (uint32_t)idx;
     }
 }
@@ -555,7 +555,7 @@ __global__ __launch_bounds__(64) void k_bp_walk(DgParams p) {
 // ---- consensus segmentation (:327-373) and output, one wave per target ------------
 __global__ __launch_bounds__(64) void k_bp_join(DgParams p) {
     const uint32_t t = blockIdx.x;
-    if (dg_failed(p) || !p.tactive[t]) return;
+    if (dg_failed(p) || dg_tskip(p, t)) return;
     const int lane = threadIdx.x;
     const uint64_t nb = p.node_base[t];
     const uint32_t *crow = p.cuts_bp + (uint64_t)t * (p.bp_max + 2u);

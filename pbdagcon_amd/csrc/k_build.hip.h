@@ -26,6 +26,23 @@ __device__ __forceinline__ bool dg_failed(const DgParams &p) {
 __device__ __forceinline__ void dg_fail(const DgParams &p, uint32_t bit) {
     atomicOr(&p.st->err_flags, bit);
 }
+// a failure that is confined to target t (the reference's asserts / undefined behaviour hit one
+// worker's one target, AlnGraphBoost.cpp:71-72): the target is dropped, the batch completes
+__device__ __forceinline__ void dg_fail_target(const DgParams &p, uint32_t t, uint32_t bit) {
+    atomicOr(&p.tfail[t], bit);
+}
+__device__ __forceinline__ bool dg_tskip(const DgParams &p, uint32_t t) {
+    return !p.tactive[t] || __hip_atomic_load(&p.tfail[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+}
+// alignment-level kernels: alignments of a failed target are not worth another instruction
+__device__ __forceinline__ bool dg_askip(const DgParams &p, uint32_t a) {
+    return !(p.flags & DG_F_A1_ONLY) && __hip_atomic_load(&p.tfail[p.aln_tgt[a]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+}
+__device__ __forceinline__ void dg_fail_aln(const DgParams &p, uint32_t a, uint32_t bit) {
+    if (p.flags & DG_F_A1_ONLY) dg_fail(p, bit);       // dagcon_normalize: no targets, the call fails
+    else dg_fail_target(p, p.aln_tgt[a], bit);
+    p.st->bad_aln = a;
+}
 
 // ---------------------------------------------------------------------------
 // normalizeGaps.  Columns are uint16: low byte = query char, high byte = target char.
@@ -63,14 +80,13 @@ __device__ inline void dg_finish_alignment(const DgParams &p, uint32_t a, uint16
     // deletions advance the backbone cursor (AlnGraphBoost.cpp:75-104); the insertion run
     // length per (position, read) numbers the inserted vertices
     const bool graph = !(p.flags & DG_F_A1_ONLY);
-    uint32_t t_idx = 0, r = 0, K = 0;
+    uint32_t t_idx = 0, r = 0;
     uint32_t *Cm = nullptr;
     if (graph) {
         t_idx = p.aln_tgt[a];
         if (p.tactive[t_idx]) {
             const uint64_t ab = p.aln_begin[t_idx];
             r = (uint32_t)(a - ab);
-            K = (uint32_t)(p.aln_begin[t_idx + 1] - ab);
             Cm = p.matC + p.matc_base[t_idx] + (uint64_t)r * p.matc_stride[t_idx];   // the read's row
         }
     }
@@ -111,10 +127,7 @@ __device__ inline void dg_finish_alignment(const DgParams &p, uint32_t a, uint16
     p.n_lo[a] = lo; p.n_hi[a] = hi; p.n_start[a] = start;
     p.n_ins[a] = n_ins; p.n_del[a] = n_del;
     atomicAdd(&p.st->n_columns, (unsigned long long)(hi - lo));
-    if (graph && hi > lo && !conf) {
-        dg_fail(p, DG_E_NONCONF);
-        p.st->bad_aln = a;
-    }
+    if (graph && hi > lo && !conf) dg_fail_aln(p, a, DG_E_NONCONF);
 }
 
 // ---------------------------------------------------------------------------
@@ -288,6 +301,7 @@ __global__ __launch_bounds__(LANES) void k_norm_chunk(DgParams p) {
     if (dg_failed(p)) return;
     if (RETRY && p.ch_flag[g] != 2u) return;
     const uint32_t a = p.ch_aln[g];
+    if (dg_askip(p, a)) { if (!RETRY) p.ch_flag[g] = 0; return; }
     const uint32_t c = g - p.ch_base[a], nwin = p.ch_base[a + 1] - p.ch_base[a];
     const uint64_t off = p.aln_off[a];
     const uint32_t len = p.aln_len[a];
@@ -311,7 +325,7 @@ __global__ __launch_bounds__(LANES) void k_norm_chunk(DgParams p) {
                     if (s != DG_CH_NONE) { k1 = s; break; }
                 }
                 r = dg_norm_run<NW>(q, t, len, k0, k1, win, p.norm_tmp + src);
-                if (r.badchar) { dg_fail(p, DG_E_BADCHAR); p.st->bad_aln = a; }
+                if (r.badchar) dg_fail_aln(p, a, DG_E_BADCHAR);
                 if (r.overflow) { flag = RETRY ? 1u : 2u; break; }
                 if (!r.dirty) break;
                 // a gap in flight got past the end: once more with the next chunk taken in,
@@ -337,6 +351,7 @@ __global__ __launch_bounds__(64) void k_norm_scan(DgParams p) {
     const uint32_t a = blockIdx.x * 64 + threadIdx.x;
     if (a >= p.A) return;
     if (dg_failed(p)) return;
+    if (dg_askip(p, a)) return;
     const uint32_t g0 = p.ch_base[a], g1 = p.ch_base[a + 1];
     bool redo = false;
     uint32_t m = 0, tbt = 0;
@@ -400,9 +415,10 @@ __global__ __launch_bounds__(64) void k_norm_finish(DgParams p) {
     const uint32_t g = threadIdx.x * gridDim.x + blockIdx.x;
     if (g >= p.n_chunks) return;
     if (dg_failed(p)) return;
+    const uint32_t a = p.ch_aln[g];
+    if (dg_askip(p, a)) return;
     const uint32_t o = p.ch_out[g];
     if (o == DG_CH_NONE) return;
-    const uint32_t a = p.ch_aln[g];
     const uint32_t hi = p.n_hi[a];
     if (hi == DG_REDO) return;
     const uint32_t lo = p.n_lo[a], start = p.n_start[a], lb = p.n_lb[a];
@@ -412,14 +428,13 @@ __global__ __launch_bounds__(64) void k_norm_finish(DgParams p) {
     uint16_t *dst = p.norm + p.norm_off[a] + o;                       // norm_off is a multiple of 8 columns
     // what addAln will do with the window (see dg_finish_alignment)
     const bool graph = !(p.flags & DG_F_A1_ONLY);
-    uint32_t t_idx = 0, r = 0, K = 0;
+    uint32_t t_idx = 0, r = 0;
     uint32_t *Cm = nullptr;
     if (graph) {
         t_idx = p.aln_tgt[a];
         if (p.tactive[t_idx]) {
             const uint64_t ab = p.aln_begin[t_idx];
             r = (uint32_t)(a - ab);
-            K = (uint32_t)(p.aln_begin[t_idx + 1] - ab);
             Cm = p.matC + p.matc_base[t_idx] + (uint64_t)r * p.matc_stride[t_idx];   // the read's row
         }
     }
@@ -485,10 +500,7 @@ __global__ __launch_bounds__(64) void k_norm_finish(DgParams p) {
     if (run && Cm && conf && start + adv <= tlen + 1) Cm[start + adv] = run;
     if (n_ins) atomicAdd(&p.n_ins[a], n_ins);
     if (n_del) atomicAdd(&p.n_del[a], n_del);
-    if (graph && any && !conf) {
-        dg_fail(p, DG_E_NONCONF);
-        p.st->bad_aln = a;
-    }
+    if (graph && any && !conf) dg_fail_aln(p, a, DG_E_NONCONF);
 }
 
 // The same algorithm with the whole expanded alignment in HBM: raw mode and
@@ -497,6 +509,7 @@ __global__ __launch_bounds__(64) void k_normalize_slow(DgParams p) {
     const uint32_t a = blockIdx.x * 64 + threadIdx.x;
     if (a >= p.A) return;
     if (dg_failed(p)) return;
+    if (dg_askip(p, a)) return;
     if (p.n_hi[a] != DG_REDO) return;
     const uint64_t off = p.aln_off[a];
     const uint32_t len = p.aln_len[a];
@@ -506,7 +519,7 @@ __global__ __launch_bounds__(64) void k_normalize_slow(DgParams p) {
     uint32_t n = 0;
     for (uint32_t i = 0; i < len; i++) {
         uint8_t qb = q[i], tb = t[i];
-        if (qb < 33 || qb > 126 || tb < 33 || tb > 126) { dg_fail(p, DG_E_BADCHAR); p.st->bad_aln = a; }
+        if (qb < 33 || qb > 126 || tb < 33 || tb > 126) dg_fail_aln(p, a, DG_E_BADCHAR);
         if (!raw) {
             if (qb == '.') qb = DG_GAP;
             if (tb == '.') tb = DG_GAP;
@@ -579,15 +592,17 @@ __global__ __launch_bounds__(1024) void k_carve(DgParams p) {
         const uint32_t t = t0 + tid;
         unsigned long long nodes = 0, poolw = 0;
         uint32_t fixed_words = 0, ins = 0;
-        if (t < p.T && p.tactive[t]) {
+        if (t < p.T && !dg_tskip(p, t)) {
             uint32_t del = 0;
             const uint64_t b = p.aln_begin[t], e = p.aln_begin[t + 1];
             for (uint64_t a = b; a < e; a++) { ins += p.n_ins[a]; del += p.n_del[a]; }
             nodes = (unsigned long long)p.tlen[t] + 2ull + ins;
-            if (nodes > DG_MAX_NODES) { dg_fail(p, DG_E_TOO_BIG); p.st->bad_target = t; }
             poolw = dg_pool_words(p.tlen[t], ins, del, (uint32_t)(e - b), p.growth_pct, &fixed_words);
-            // (the sweeps address a target's pool with 32-bit byte offsets)
-            if (poolw > 0x3FFFFFFFull) { dg_fail(p, DG_E_TOO_BIG); p.st->bad_target = t; }
+            // (the sweeps address a target's pool with 32-bit byte offsets, arrival cells hold 25-bit ids)
+            if (nodes > DG_MAX_NODES || poolw > 0x3FFFFFFFull) {
+                dg_fail_target(p, t, DG_E_TOO_BIG);
+                nodes = 0; poolw = 0; fixed_words = 0;
+            }
         }
         s_scan[tid] = nodes;
         __syncthreads();
@@ -636,7 +651,7 @@ __global__ __launch_bounds__(1024) void k_carve(DgParams p) {
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_groups(DgParams p) {
     const uint32_t t = blockIdx.x;
-    if (dg_failed(p) || !p.tactive[t]) return;
+    if (dg_failed(p) || dg_tskip(p, t)) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t blen = p.tlen[t];
     const uint32_t K = (uint32_t)(p.aln_begin[t + 1] - p.aln_begin[t]);
@@ -684,7 +699,7 @@ __global__ __launch_bounds__(1024) void k_gscan(DgParams p) {
     __shared__ uint32_t s_scan[1024];
     __shared__ uint32_t s_carry;
     const uint32_t t = blockIdx.x;
-    if (dg_failed(p) || !p.tactive[t]) return;
+    if (dg_failed(p) || dg_tskip(p, t)) return;
     const uint32_t tid = threadIdx.x;
     const uint32_t np = p.tlen[t] + 2;
     const uint64_t bv = p.bbv_base[t];
@@ -709,7 +724,7 @@ __global__ __launch_bounds__(1024) void k_gscan(DgParams p) {
         if (tid == 0) s_carry += tot;
         __syncthreads();
     }
-    if (tid == 0 && s_carry != p.n_nodes[t]) { dg_fail(p, DG_E_INTERNAL); p.st->bad_target = t; }
+    if (tid == 0 && s_carry != p.n_nodes[t]) dg_fail_target(p, t, DG_E_INTERNAL);
 }
 
 // ---------------------------------------------------------------------------
@@ -747,7 +762,7 @@ __global__ __launch_bounds__(64) void k_emit(DgParams p) {
     __shared__ uint16_t s_col[64 * DG_ECOLS_STRIDE];
     if (dg_failed(p)) return;
     const uint32_t t = blockIdx.x;
-    if (!p.tactive[t]) return;
+    if (dg_tskip(p, t)) return;
     const int lane = threadIdx.x;
     uint16_t *colw = s_col + lane * DG_ECOLS_STRIDE;
     const uint64_t ab = p.aln_begin[t];
@@ -999,7 +1014,7 @@ __device__ __forceinline__ uint32_t dg_pool_alloc(const DgParams &p, uint32_t t,
 __global__ __launch_bounds__(256) void k_lists(DgParams p) {
     extern __shared__ int32_t s_tmp[];      // per wave: vals[max_k+2], cnts[max_k+2]
     const uint32_t t = blockIdx.x;
-    if (dg_failed(p) || !p.tactive[t]) return;
+    if (dg_failed(p) || dg_tskip(p, t)) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t blen = p.tlen[t];
     const uint32_t K = (uint32_t)(p.aln_begin[t + 1] - p.aln_begin[t]);
@@ -1141,7 +1156,7 @@ __global__ __launch_bounds__(256) void k_lists(DgParams p) {
                 }
             }
         }
-        if (n > 65000) { if (lane == 0) dg_fail(p, DG_E_INTERNAL); return; }
+        if (n > 65000) { if (lane == 0) dg_fail_target(p, t, DG_E_INTERNAL); return; }
         uint32_t off = dir == 0 ? out_off : in_off;
         if ((uint32_t)n > capb) {                               // rare: move to the growth region
             const uint32_t cap = (uint32_t)n + 2u;

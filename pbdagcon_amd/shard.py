@@ -33,10 +33,10 @@ def shard_ranges(weights, world: int):
     return [(bounds[r], bounds[r + 1]) for r in range(world)]
 
 
-def gather_fasta(payload: bytes, dist, torch, local_rank=None):
+def gather_fasta(payload: bytes, dist, torch, local_rank=None, return_sizes=False):
     """Gather every rank's FASTA bytes on rank 0, in rank order (= global
     target order, since shards are contiguous).  Returns bytes on rank 0 and
-    None elsewhere."""
+    None elsewhere; with return_sizes also the byte count every rank announced."""
     world = dist.get_world_size()
     rank = dist.get_rank()
     backend = dist.get_backend()
@@ -53,6 +53,7 @@ def gather_fasta(payload: bytes, dist, torch, local_rank=None):
     if rank == 0:
         parts = [torch.zeros(cap, dtype=torch.uint8, device=dev) for _ in range(world)]
         dist.gather(buf, parts, dst=0)
-        return b"".join(bytes(parts[r][:sizes[r]].cpu().numpy().tobytes()) for r in range(world))
+        out = b"".join(bytes(parts[r][:sizes[r]].cpu().numpy().tobytes()) for r in range(world))
+        return (out, sizes) if return_sizes else out
     dist.gather(buf, None, dst=0)
-    return None
+    return (None, sizes) if return_sizes else None

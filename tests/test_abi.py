@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     lib = capi.load()
     for name in declared_functions():
         assert hasattr(lib, name), f"{name} is declared in include/dagcon.h but not exported"
-    assert lib.dagcon_abi_version() == 1
+    assert lib.dagcon_abi_version() == 2
 
 
 def test_struct_layouts_match_header():

@@ -16,6 +16,23 @@ from util import batch_from_targets, oracle_batch, random_target
 pytestmark = pytest.mark.gpu
 
 
+def _digest(results):
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        "make_large_hashes", os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "make_large_hashes.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m.digest(results)
+
+
+def _golden(name):
+    import json
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "large_hashes.json")
+    return json.load(open(path))[name]["sha256"]
+
+
 # ---- reference KATs, through the device -------------------------------------
 
 def test_normalize_kat_device():
@@ -508,6 +525,9 @@ def test_full_size_configs1_properties(gpu_ctx_factory):
         r0, r1_, s = segs[0]
         assert r0 == 0 and r1_ == len(s) and 9700 <= len(s) <= 10100, f"target {t}: {r0} {r1_} {len(s)}"
         assert set(s) <= set(b"ACGT")
+    # whole-batch parity: the digest of all 1,000 targets' segments equals the one the CPU oracle
+    # produced in the build container (tests/golden/make_large_hashes.py), and a sample live
+    assert _digest(r1) == _golden("configs1_1000x10kx40")
     sample = list(range(0, 1000, 97))
     sub = batch.select(sample)
     assert oracle_batch(sub, 6, 500, 50) == [r1[t] for t in sample]
@@ -518,10 +538,18 @@ def test_config3_and_config5_shapes(gpu_ctx_factory):
     (long target, more than 64... no: 60 reads, deep pools) and 20 kb x 30x with mixed target
     lengths and partial spans, -t 10 as dazcon does, real backbone bases given."""
     b3 = synth.make_batch(2, 50000, 60, seed=7000)
-    _check_batch(gpu_ctx_factory, b3, min_cov=8, min_len=500, trim=50)
+    _, r3 = _check_batch(gpu_ctx_factory, b3, min_cov=8, min_len=500, trim=50)
+    assert _digest(r3) == _golden("config3_2x50kx60")
     tl = np.random.default_rng(5).integers(2000, 40000, 6)
     b5 = synth.make_batch(6, 0, 30, seed=8000, min_span=0.6, tlens=tl, with_backbone=True)
-    _check_batch(gpu_ctx_factory, b5, min_cov=6, min_len=500, trim=10)
+    _, r5 = _check_batch(gpu_ctx_factory, b5, min_cov=6, min_len=500, trim=10)
+    assert _digest(r5) == _golden("config5_6xmixedx30_partial")
+    # the config-5 shape at the size tools/shapes.py times (400 mixed-length targets, partial spans):
+    # whole batch against the committed oracle digest
+    tl = np.random.default_rng(5).integers(2000, 40000, 400)
+    b5 = synth.make_batch(400, 0, 30, seed=8000, min_span=0.6, tlens=tl, with_backbone=True)
+    ctx = gpu_ctx_factory(min_cov=6, min_len=500, trim=10)
+    assert _digest(ctx.consensus(b5)) == _golden("config5_400xmixedx30_partial")
 
 
 def test_production_coverage_caps(gpu_ctx_factory):
@@ -559,3 +587,130 @@ def test_ragged_batch_and_workspace_growth(gpu_ctx_factory):
     b = ctx.consensus(batch)
     assert a == b == oracle_batch(batch, 1, 0, 2, 1)
     assert ctx.timings()["reruns"] == 0 and first >= 0
+
+
+# ---- ABI 2: failures are confined to their target ------------------------------
+
+def test_one_bad_target_does_not_take_the_batch_down(gpu_ctx_factory):
+    """The reference's assert / undefined behaviour on a non-conforming alignment hits one worker's
+    one target (AlnGraphBoost.cpp:71-72).  Here: 50 targets, one of which holds an alignment that
+    runs past tlen, one a non-printable byte, one start = 0; dagcon_consensus returns DAGCON_OK,
+    target_status names the three, and the other 47 are bit-exact."""
+    rng = np.random.default_rng(91)
+    targets = []
+    for i in range(50):
+        tl = int(rng.integers(600, 1500))
+        alns, bb = random_target(rng, tl, int(rng.integers(7, 12)), alphabet=b"ACGT", full_span=(i % 2 == 0))
+        targets.append((tl, alns, bb))
+    good = batch_from_targets(targets)
+    exp = oracle_batch(good, 6, 500, 10)
+    bad = list(targets)
+    tl, alns, bb = bad[7]
+    s0, q0, t0 = alns[3]
+    bad[7] = (tl, alns[:3] + [(tl - 100, q0, t0)] + alns[4:], bb)             # target bases past tlen
+    tl, alns, bb = bad[23]
+    s0, q0, t0 = alns[0]
+    bad[23] = (tl, [(s0, q0[:40] + b"\x07" + q0[41:], t0)] + alns[1:], bb)    # a byte outside 33..126
+    tl, alns, bb = bad[49]
+    s0, q0, t0 = alns[-1]
+    bad[49] = (tl, alns[:-1] + [(0, q0, t0)], bb)                             # start < 1
+    batch = batch_from_targets(bad)
+    ctx = gpu_ctx_factory(min_cov=6, min_len=500, trim=10)
+    with pytest.raises(capi.DagconError) as e:                                # strict callers still get an error
+        ctx.consensus(batch)
+    assert e.value.code == -4
+    got = ctx.consensus(batch, strict=False)
+    assert list(np.flatnonzero(ctx.target_status)) == [7, 23, 49]
+    assert all(ctx.target_status[t] == -4 for t in (7, 23, 49))
+    for t in range(50):
+        if t in (7, 23, 49):
+            assert got[t] == []
+        else:
+            assert got[t] == exp[t], f"target {t}"
+    # the context is clean afterwards
+    assert ctx.consensus(good) == exp and not ctx.target_status.any()
+
+
+def test_flags_are_checked_and_host_alloc(gpu_ctx_factory):
+    """dagcon_create refuses undefined flag bits (bit 8 is an internal one: DG_F_A1_ONLY would switch the
+    conformity check off); dagcon_host_alloc gives page-locked blobs that dagcon_upload takes as they are."""
+    with pytest.raises(capi.DagconError) as e:
+        capi.Context(min_cov=0, min_len=0, trim=0, flags=8)
+    assert e.value.code == -5
+    with pytest.raises(capi.DagconError) as e:
+        capi.Context(flags=1 << 20)
+    assert e.value.code == -5
+    batch = synth.make_batch(4, 1200, 12, seed=5)
+    ctx = gpu_ctx_factory(min_cov=6, min_len=500, trim=50)
+    pinned = ctx.pin_batch(batch)
+    assert ctx.consensus(pinned) == ctx.consensus(batch) == oracle_batch(batch, 6, 500, 50)
+    # an offset that wraps: refused, not read
+    import copy
+    b2 = copy.copy(batch)
+    b2.aln_off = batch.aln_off.copy(); b2.aln_off[3] = np.uint64(2**64 - 16)
+    with pytest.raises(capi.DagconError) as e:
+        ctx.consensus(b2)
+    assert e.value.code == -1
+
+
+def test_very_deep_coverage(gpu_ctx_factory):
+    """DAGCON_MAX_COVERAGE is what the header says: thousands of alignments on one target (k_lists
+    with more than 64 KB of dynamic LDS, the multi-wave rows of k_groups / k_emit / k_lists / k_merge)."""
+    rng = np.random.default_rng(33)
+    for k, tl in ((2100, 24), (capi.MAX_COVERAGE, 12)):
+        alns, bb = random_target(rng, tl, k, alphabet=b"ACGT", sub=0.05, ins=0.08, dele=0.05, full_span=False)
+        batch = batch_from_targets([(tl, alns, bb)])
+        _check_batch(gpu_ctx_factory, batch, min_cov=6, min_len=0, trim=0, min_weight=-1)
+        _check_batch(gpu_ctx_factory, batch, min_cov=0, min_len=0, trim=1, min_weight=0)
+
+
+def test_cli_several_workers_and_a_bad_target(tmp_path):
+    """--devices: one consensus worker (thread + context) per listed GPU, batches dealt to them in
+    input order, records printed in input order (here the same GPU twice: the box has one).  A
+    target with a non-conforming alignment is reported on stderr and skipped; exit code 0."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cli = os.path.join(root, "pbdagcon_amd", "bin", "pbdagcon")
+    batch = synth.make_batch(12, 1200, 10, seed=77)
+    m5 = synth.to_m5(batch)
+    path = tmp_path / "in.m5"
+    path.write_bytes(m5)
+    one = subprocess.run([cli, "-j", "2", str(path)], capture_output=True, timeout=300)
+    assert one.returncode == 0, one.stderr.decode()
+    exp = b"".join(b">%s/%d_%d\n%s\n" % (batch.ids[t].encode(), r0, r1, s)
+                   for t, segs in enumerate(oracle_batch(batch, 6, 500, 50)) for r0, r1, s in segs)
+    assert one.stdout == exp and exp.count(b">") == 12
+    two = subprocess.run([cli, "-j", "2", "--devices", "0,0", "--batch-targets", "2", "--pinned", "1", str(path)],
+                         capture_output=True, timeout=300)
+    assert two.returncode == 0 and two.stdout == exp, two.stderr.decode()
+    # break one alignment of target 5: tStart beyond the target
+    lines = m5.decode().splitlines()
+    f = lines[53].split(" ")
+    f[7] = str(1150)
+    lines[53] = " ".join(f)
+    path.write_text("\n".join(lines) + "\n")
+    bad = subprocess.run([cli, "--devices", "0,0", "--batch-targets", "3", str(path)], capture_output=True, timeout=300)
+    assert bad.returncode == 0
+    assert b"skipped" in bad.stderr and batch.ids[5].encode() in bad.stderr
+    keep = b"".join(rec for rec in [b">" + r for r in exp.split(b">")[1:]] if not rec.startswith(b">" + batch.ids[5].encode()))
+    assert bad.stdout == keep
+
+
+def test_bench_two_ranks_share_the_gpu():
+    """bench.py --gpus 2 starts two ranks itself; with --backend gloo they share the one GPU of the box:
+    every rank checks its shard against the oracle, rank 0 checks the gathered FASTA against the
+    SHA-256 each rank took of its own part."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "2",
+                          "--warmup", "1", "--targets", "24", "--tlen", "2000", "--coverage", "16", "--no-legs",
+                          "--cpu-sample", "24"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["fasta_gather_ok"] is True and line["bit_exact_vs_oracle"] is True
+    assert line["targets_verified"] == 24 + 16

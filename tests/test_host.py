@@ -157,3 +157,68 @@ def test_cli_flags_and_errors(tmp_path):
     assert subprocess.run([cli, "--dump-parsed", str(bad)], capture_output=True).returncode == 1
     v = subprocess.run([cli, "--version"], capture_output=True, text=True)
     assert "0.3" in v.stdout
+
+
+def _bench(*args, env_extra=None, timeout=300):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], env=env,
+                          capture_output=True, text=True, timeout=timeout)
+
+
+def test_bench_gpus_flag_starts_the_ranks_itself():
+    """`bench.py --gpus 2` with nothing in the environment starts two ranks (child processes,
+    gloo on CPU here), splits the target index space with shard_ranges and verifies the gathered
+    FASTA against the SHA-256 every rank took of its own part (--rehearse: records are
+    fabricated, no device).  The reference starts its N consensus workers itself too
+    (main.cpp:251-274)."""
+    import json
+    out = _bench("--gpus", "2", "--backend", "gloo", "--rehearse", "--targets", "37")
+    assert out.returncode == 0, out.stdout + out.stderr
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["fasta_gather_ok"] is True
+    assert line["targets_total"] == 74 and line["records"] == 74 and line["shard"] == [0, 37]
+    # three ranks, and the driver's way (ranks from the environment of torch.distributed.run)
+    out = _bench("--gpus", "3", "--backend", "gloo", "--rehearse", "--targets", "5")
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out.returncode == 0 and line["n_gpus"] == 3 and line["fasta_gather_ok"] is True and line["records"] == 15
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+         "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--rehearse",
+         "--targets", "11"], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["fasta_gather_ok"] is True and line["records"] == 22
+
+
+def test_bench_without_a_gpu_fails_loudly():
+    """The measured path has no CPU stand-in: without a device bench.py ends with an error."""
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("a GPU is present")
+    out = _bench("--steps", "1", "--warmup", "0", "--targets", "2", "--tlen", "600", "--coverage", "8")
+    assert out.returncode != 0
+
+
+def test_shard_ranges_cover_and_balance():
+    import numpy as np
+    from pbdagcon_amd.shard import shard_ranges
+    rng = np.random.default_rng(3)
+    for n, world in ((1000, 8), (7, 3), (3, 8), (0, 2), (100000, 8)):
+        w = rng.integers(1, 100, n).astype(float)
+        r = shard_ranges(w, world)
+        assert len(r) == world and r[0][0] == 0 and r[-1][1] == n
+        assert all(r[i][1] == r[i + 1][0] for i in range(world - 1))
+        if n >= 100 * world:
+            tot = [w[a:b].sum() for a, b in r]
+            assert max(tot) <= 1.05 * w.sum() / world + 100
+
+
+def test_cli_flag_parsing_devices():
+    cli = _cli()
+    assert subprocess.run([cli, "--devices"], capture_output=True).returncode == 2
+    assert subprocess.run([cli, "--devices", "0,x", "f.m5"], capture_output=True).returncode == 2
+    assert subprocess.run([cli, "--devices", "", "f.m5"], capture_output=True).returncode == 2
