@@ -594,7 +594,7 @@ def test_ragged_batch_and_workspace_growth(gpu_ctx_factory):
 def test_one_bad_target_does_not_take_the_batch_down(gpu_ctx_factory):
     """The reference's assert / undefined behaviour on a non-conforming alignment hits one worker's
     one target (AlnGraphBoost.cpp:71-72).  Here: 50 targets, one of which holds an alignment that
-    runs past tlen, one a non-printable byte, one start = 0; dagcon_consensus returns DAGCON_OK,
+    runs past tlen, one a non-printable byte, one that starts behind the target; dagcon_consensus returns DAGCON_OK,
     target_status names the three, and the other 47 are bit-exact."""
     rng = np.random.default_rng(91)
     targets = []
@@ -613,7 +613,7 @@ def test_one_bad_target_does_not_take_the_batch_down(gpu_ctx_factory):
     bad[23] = (tl, [(s0, q0[:40] + b"\x07" + q0[41:], t0)] + alns[1:], bb)    # a byte outside 33..126
     tl, alns, bb = bad[49]
     s0, q0, t0 = alns[-1]
-    bad[49] = (tl, alns[:-1] + [(0, q0, t0)], bb)                             # start < 1
+    bad[49] = (tl, alns[:-1] + [(tl + 5, q0, t0)], bb)                        # starts behind the target
     batch = batch_from_targets(bad)
     ctx = gpu_ctx_factory(min_cov=6, min_len=500, trim=10)
     with pytest.raises(capi.DagconError) as e:                                # strict callers still get an error
