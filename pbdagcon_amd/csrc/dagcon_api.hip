@@ -18,6 +18,7 @@
 #include "dagcon_dev.h"
 #include "k_build.hip.h"
 #include "k_merge.hip.h"
+#include "k_merge_tile.hip.h"
 #include "k_bestpath.hip.h"
 
 namespace {
@@ -62,12 +63,13 @@ struct Ctx {
     DevBuf d_node_base, d_n_nodes, d_pool_base, d_pool_size, d_pool_top, d_t_nins;
     DevBuf d_matA, d_matD, d_matC, d_cov, d_gcount, d_gbase, d_bid;
     DevBuf d_nodes, d_best, d_queue, d_score, d_cns_tmp, d_bp_tt;
-    DevBuf d_pool, d_stk, d_cuts, d_cuts_bp, d_bp_stat, d_bp_len, d_cuts_ln, d_stk_ln;
+    DevBuf d_pool, d_stk, d_cuts, d_cuts_bp, d_bp_stat, d_bp_len, d_nextcut, d_tile_list;
     DevBuf d_cns, d_cns_off, d_cns_len, d_seg_first, d_n_seg, d_seg_r0, d_seg_r1, d_st;
 
     uint64_t norm_cap = 0, node_cap = 0, pool_cap = 0, cns_cap = 0, seg_cap = 0;
     uint32_t stk_words = 4096, growth_pct = 100, seg_max = 8, bp_max = 16, seg_env = 0;    // (scratch per target and segment: grown x4 and re-run on DG_E_STACK)
-    uint32_t ln_max = 0, ln_space = 16, stk_ln_words = 0;   // lane-per-stretch merge (0 slots: off)
+    uint32_t tile_pos = 0, tile_words = 0, tile_ny = 0, tile_list_cap = 0, list_grid = 4096;   // LDS tiles (tile_pos 0: off)
+    double ins_per_pos = -1.0;                      // inserted vertices per backbone position, from the last run
     uint64_t expected_workers = 0;                  // merge workers the batch will probably run (prefetch on / off)
 
     DgStatus h_st;
@@ -146,15 +148,15 @@ int ensure_arenas(Ctx *c) {
     ENSURE(c, c->d_bp_tt, c->node_cap * 4);
     ENSURE(c, c->d_cns_tmp, c->node_cap);
     ENSURE(c, c->d_pool, c->pool_cap * 4);
-    ENSURE(c, c->d_stk, (uint64_t)c->T * c->bp_max * c->stk_words * 4);       // (bp_max >= seg_max)
+    ENSURE(c, c->d_stk, std::max<uint64_t>((uint64_t)c->T * c->bp_max, c->tile_pos ? c->list_grid : 0) * c->stk_words * 4);       // (bp_max >= seg_max)
+    if (c->tile_pos) {
+        ENSURE(c, c->d_nextcut, c->sum_bb * 4);
+        ENSURE(c, c->d_tile_list, (4ull + 3ull * c->tile_list_cap) * 4);
+    }
     ENSURE(c, c->d_cuts, (uint64_t)c->T * (c->seg_max + 2) * 4);
     ENSURE(c, c->d_cuts_bp, (uint64_t)c->T * (c->bp_max + 2) * 4);
     ENSURE(c, c->d_bp_stat, (uint64_t)c->T * c->bp_max * 8);
     ENSURE(c, c->d_bp_len, (uint64_t)c->T * c->bp_max * 4);
-    if (c->ln_max) {
-        ENSURE(c, c->d_cuts_ln, (uint64_t)c->T * (c->ln_max + 2) * 4);
-        ENSURE(c, c->d_stk_ln, (uint64_t)c->T * ((c->ln_max + 63) / 64) * 64 * c->stk_ln_words * 4);
-    }
     ENSURE(c, c->d_cns, c->cns_cap);
     ENSURE(c, c->d_seg_r0, c->seg_cap * 4);
     ENSURE(c, c->d_seg_r1, c->seg_cap * 4);
@@ -210,8 +212,8 @@ void fill_params(Ctx *c, DgParams &p) {
     // workers hide each other's latency and it only takes issue slots from them
     { const char *e = getenv("DAGCON_PF_AHEAD"); p.pf_ahead = e ? (uint32_t)atoi(e) : (c->expected_workers >= 4096 ? 0u : 48u); }
     p.seg_max = c->seg_max; p.seg_min = c->opts.min_segment_len ? c->opts.min_segment_len : 768u; p.cuts = (uint32_t *)c->d_cuts.p; p.bp_max = c->bp_max; p.cuts_bp = (uint32_t *)c->d_cuts_bp.p; p.bp_stat = (float *)c->d_bp_stat.p; p.bp_len = (uint32_t *)c->d_bp_len.p;
-    p.ln_max = c->ln_max; p.ln_space = c->ln_space; p.cuts_ln = (uint32_t *)c->d_cuts_ln.p;
-    p.stk_ln = (int32_t *)c->d_stk_ln.p; p.stk_ln_words = c->stk_ln_words;
+    p.nextcut = (uint32_t *)c->d_nextcut.p; p.tile_pos = c->tile_pos; p.tile_words = c->tile_words;
+    p.tile_list = (uint32_t *)c->d_tile_list.p; p.tile_list_cap = c->tile_list_cap;
     p.cns = (uint8_t *)c->d_cns.p; p.cns_cap = c->cns_cap;
     p.cns_off = (uint64_t *)c->d_cns_off.p; p.cns_len = (uint32_t *)c->d_cns_len.p;
     p.seg_first = (uint64_t *)c->d_seg_first.p; p.n_seg = (uint32_t *)c->d_n_seg.p;
@@ -263,9 +265,12 @@ int launch_all(Ctx *c) {
     HIPCHK(c, hipEventRecord(c->ev[2], s));
     if (c->T > 0 && !(c->opts.flags & DAGCON_FLAG_STOP_AFTER_BUILD)) {
         hipLaunchKernelGGL(k_cuts, dim3(c->T), dim3(64), 0, s, p);
-        if (c->ln_max) {
-            hipLaunchKernelGGL(k_cuts_fine, dim3(c->T), dim3(256), 0, s, p);
-            hipLaunchKernelGGL(k_merge_lanes, dim3(c->T * ((c->ln_max + 63) / 64)), dim3(64), 0, s, p);
+        if (c->tile_pos) {
+            HIPCHK(c, hipMemsetAsync(c->d_tile_list.p, 0, 16, s));
+            HIPCHK(c, hipFuncSetAttribute((const void *)k_merge_tile, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(c->tile_words * 4)));
+            hipLaunchKernelGGL(k_cutmap, dim3(c->T), dim3(1024), 0, s, p);
+            hipLaunchKernelGGL(k_merge_tile, dim3(c->T, c->tile_ny), dim3(DG_T_LANES), c->tile_words * 4, s, p);
+            hipLaunchKernelGGL(k_merge_list, dim3(c->list_grid), dim3(64), 0, s, p);
         } else if (p.pf_ahead) hipLaunchKernelGGL(k_merge<true>, dim3(c->T * c->seg_max), dim3(128), 0, s, p);
         else hipLaunchKernelGGL(k_merge<false>, dim3(c->T * c->seg_max), dim3(64), 0, s, p);
     }
@@ -346,7 +351,7 @@ void dagcon_destroy(dagcon_ctx *ctx) {
                      &c->d_n_ins, &c->d_n_del, &c->d_norm, &c->d_node_base, &c->d_n_nodes,
                      &c->d_pool_base, &c->d_pool_size, &c->d_pool_top, &c->d_t_nins, &c->d_matA, &c->d_matD,
                      &c->d_matC, &c->d_cov, &c->d_gcount, &c->d_gbase, &c->d_bid, &c->d_nodes,
-                     &c->d_best, &c->d_queue, &c->d_score, &c->d_cns_tmp, &c->d_bp_tt, &c->d_pool, &c->d_stk, &c->d_cuts, &c->d_cuts_bp, &c->d_bp_stat, &c->d_bp_len, &c->d_cuts_ln, &c->d_stk_ln, &c->d_cns,
+                     &c->d_best, &c->d_queue, &c->d_score, &c->d_cns_tmp, &c->d_bp_tt, &c->d_pool, &c->d_stk, &c->d_cuts, &c->d_cuts_bp, &c->d_bp_stat, &c->d_bp_len, &c->d_nextcut, &c->d_tile_list, &c->d_cns,
                      &c->d_cns_off, &c->d_cns_len, &c->d_seg_first, &c->d_n_seg, &c->d_seg_r0, &c->d_seg_r1,
                      &c->d_st};
     for (DevBuf *b : all) free_buf(*b);
@@ -386,7 +391,6 @@ int dagcon_upload(dagcon_ctx *ctx, const dagcon_batch *b) {
         if (c->stk_words < base || (uint64_t)c->stk_words * pieces > (1024ull << 20)) c->stk_words = base;
     }
     c->h_tlen.assign(b->tlen, b->tlen + T);
-    c->ln_max = 0;
     c->h_aln_begin.assign(T + 1, 0);
     c->h_tactive.assign(T, 0);
     c->h_mat_base.assign(T, 0);
@@ -440,11 +444,26 @@ int dagcon_upload(dagcon_ctx *ctx, const dagcon_batch *b) {
             bb_bytes = std::max<uint64_t>(bb_bytes, b->backbone_off[t] + b->tlen[t]);
         }
     }
-    if (const char *e = getenv("DAGCON_LANE_MERGE")) {
-        if (atoi(e) > 0) {
-            if (const char *e2 = getenv("DAGCON_LN_SPACE")) { const int v = atoi(e2); if (v >= 1) c->ln_space = (uint32_t)v; }
-            c->ln_max = std::max(1u, std::min(8192u, c->max_tlen / c->ln_space + 1u));
-            c->stk_ln_words = std::max(c->stk_ln_words, std::max(256u, 3u * (2u * (c->max_k + 2u) + 3u)));
+    // LDS tiles for mergeNodes: positions per tile from the LDS budget and the expected size of a
+    // position's share of the graph (exact after the first run of a shape)
+    {
+        // (opt-in: exact, but at configs[1] the lanes' dependent LDS chains at two waves per CU take 128 ms
+        // where the wave-per-segment kernel takes 22: DESIGN.md, "tried and dropped")
+        int on = 0;
+        if (const char *e = getenv("DAGCON_TILES")) on = atoi(e);
+        uint32_t kb = 80;
+        if (const char *e = getenv("DAGCON_TILE_KB")) { const int v = atoi(e); if (v >= 16 && v <= 160) kb = (uint32_t)v; }
+        c->tile_pos = 0;
+        if (on && T && c->max_k >= 1 && c->seg_max != 1) {
+            c->tile_words = kb * 256u;
+            const double ipp = c->ins_per_pos >= 0 ? c->ins_per_pos : (double)c->sum_len / 10.0 / (double)std::max<uint64_t>(c->sum_bb, 1);
+            const double wpp = 9.5 * (1.0 + ipp) + 3.0 * ipp + 3.0 * dg_capb(c->max_k);
+            const double room = ((double)c->tile_words - 1200.0) * 0.9;
+            uint32_t G = (uint32_t)std::max(8.0, room / wpp);
+            if (const char *e = getenv("DAGCON_TILE_POS")) { const int v = atoi(e); if (v >= 2) G = (uint32_t)v; }
+            c->tile_pos = G;
+            c->tile_ny = (c->max_tlen + 2 + G - 1) / G;
+            c->tile_list_cap = std::max<uint32_t>(c->tile_list_cap, (uint32_t)std::min<uint64_t>((uint64_t)T * c->tile_ny + 16, 0x0FFFFFFFull));
         }
     }
     c->h_aln_begin[T] = c->h_aln_len.size();
@@ -589,7 +608,8 @@ int dagcon_fetch(dagcon_ctx *ctx, dagcon_results *res) {
         if (f & DG_E_NODE_OVF) c->node_cap = c->h_st.node_need + 1024;
         if (f & DG_E_POOL_OVF) c->pool_cap = c->h_st.pool_need + 1024;
         if (f & DG_E_POOL_TGT) c->growth_pct *= 3;
-        if (f & DG_E_STACK) { c->stk_words *= 4; c->stk_ln_words *= 4; }
+        if (f & DG_E_STACK) c->stk_words *= 4;
+        if (f & DG_E_LIST_OVF) c->tile_list_cap *= 4;
         if (f & DG_E_OUT_OVF) {
             c->cns_cap = std::max<uint64_t>(c->cns_cap, c->h_st.cns_top + 1024);
             c->seg_cap = std::max<uint64_t>(c->seg_cap, c->h_st.seg_top + 1024);
@@ -669,6 +689,7 @@ int dagcon_fetch(dagcon_ctx *ctx, dagcon_results *res) {
     c->tm.n_columns = c->h_st.n_columns;
     c->tm.n_nodes = c->h_st.node_need;
     c->tm.merge_segments = c->h_st.n_mseg;
+    if (c->sum_bb && c->h_st.node_need >= c->sum_bb) c->ins_per_pos = (double)(c->h_st.node_need - c->sum_bb) / (double)c->sum_bb;
     res->n_targets = T;
     res->n_segments = c->r_range0.size();
     res->seg_begin = c->r_seg_begin.data();

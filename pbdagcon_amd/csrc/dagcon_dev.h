@@ -35,6 +35,7 @@
 #define DG_E_INTERNAL    0x080u  // invariant violated (empty list dereference, list > 65535)
 #define DG_E_OUT_OVF     0x100u  // output arena too small
 #define DG_E_TOO_BIG     0x200u  // a target has more than 2^25-2 vertices
+#define DG_E_LIST_OVF    0x400u  // more tiles handed to k_merge_list than its list holds (rerun with a longer one)
 
 // failures of one target (its input, or an invariant of its graph): recorded in DgParams::tfail,
 // the batch goes on; everything else is a capacity problem of the whole batch (grow and re-run)
@@ -161,12 +162,12 @@ struct DgParams {
     uint32_t *cuts_bp;             //   its waves are light), [T][bp_max + 2] like cuts
     float *bp_stat;                // [T][seg_max][2]: largest |score| of the segment, score of its first vertex
     uint32_t *bp_len;              // [T][seg_max]: vertices of the best path inside the segment (enter / exit excluded)
-    // ---- lane-per-stretch merge (k_cuts_fine, k_merge_lanes) ----
-    uint32_t ln_max;               // slots per target (0: the lane kernels are not used)
-    uint32_t ln_space;             // backbone positions per slot
-    uint32_t *cuts_ln;             // [T][ln_max + 2]: slots, first vertex of each slot (DG_NOCUT: none)
-    int32_t *stk_ln;               // per-lane scratch, stk_ln_words each
-    uint32_t stk_ln_words;
+    // ---- LDS tiles (k_cutmap, k_merge_tile, k_merge_list) ----
+    uint32_t *nextcut;             // [bbv_base + p]: smallest cut position >= p (k_cutmap)
+    uint32_t tile_pos;             // backbone positions per tile (0: tiles are not used)
+    uint32_t tile_words;           // LDS words of a tile's image
+    uint32_t *tile_list;           // [0] entries, [1] tiles that gave up, then (target, first, last) triples
+    uint32_t tile_list_cap;
     // ---- outputs ----
     uint8_t *cns;
     uint64_t cns_cap;

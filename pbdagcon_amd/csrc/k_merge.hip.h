@@ -749,7 +749,7 @@ __global__ __launch_bounds__(64) void k_cuts(DgParams p) {
             }
             if (found) { if (lane == 0) out[1 + nseg] = found; nseg++; }
         }
-        if (lane == 0) { out[0] = nseg; if (which == 0 && !p.ln_max) atomicAdd(&p.st->n_mseg, nseg); }
+        if (lane == 0) { out[0] = nseg; if (which == 0 && !p.tile_pos) atomicAdd(&p.st->n_mseg, nseg); }
     }
 }
 
@@ -760,19 +760,16 @@ __global__ __launch_bounds__(64) void k_cuts(DgParams p) {
 // PF: a second wave runs ahead of the worker and pulls the records and lists it is about to
 // need into L2 (pays when the chip has idle wave slots: few targets x segments in flight)
 #define DG_PROG_SET(x) __hip_atomic_store(&s_prog, (x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+// One segment [c_start, c_end] of target t, swept by the calling wave (PF: by the first wave of the
+// block, the second prefetches).  c_end = 0x7fffffff: the segment runs to the exit vertex.
 template <bool PF>
-__global__ __launch_bounds__(PF ? 128 : 64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_merge(DgParams p) {
-    const uint32_t t = blockIdx.x / p.seg_max, seg = blockIdx.x % p.seg_max;
-    if (dg_failed(p) || dg_tskip(p, t)) return;
-    const uint32_t *crow = p.cuts + (uint64_t)t * (p.seg_max + 2u);
-    const uint32_t nseg = crow[0];
-    if (seg >= nseg) return;
+__device__ __forceinline__ void dg_merge_segment(const DgParams &p, const uint32_t t, const int c_start, const int c_end,
+                                                 int32_t *stk_base) {
     const int lane = threadIdx.x & 63;
     const uint64_t nb = p.node_base[t];
     const uint32_t NT = p.n_nodes[t];
-    const int c_start = (int)crow[1 + seg];
-    const int c_end = seg + 1 < nseg ? (int)crow[2 + seg] : 0x7fffffff;     // the next segment's cut vertex
-    const int c_hi = seg + 1 < nseg ? c_end : (int)NT - 1;
+    const bool has_end = c_end != 0x7fffffff;
+    const int c_hi = has_end ? c_end : (int)NT - 1;
     __shared__ int s_prog;
     if (PF) {
         if (threadIdx.x == 0) s_prog = c_start;
@@ -785,7 +782,7 @@ __global__ __launch_bounds__(PF ? 128 : 64) __attribute__((amdgpu_waves_per_eu(8
     DgGraph g;
     g.nd = p.nodes + nb; g.queue = p.queue + nb + c_start;          // the segment's own stretch of the queue
     g.pool = p.pool + p.pool_base[t]; g.pool_size = p.pool_size[t]; g.pool_top = p.pool_top + t;
-    g.stk = p.stk + (uint64_t)blockIdx.x * p.stk_words; g.stk_words = p.stk_words;
+    g.stk = stk_base; g.stk_words = p.stk_words;
     g.st = p.st; g.tfail = p.tfail + t; g.t = t; g.err = false;
     const uint32_t N = (uint32_t)(c_hi - c_start + 1);               // vertices this worker can dequeue
     __shared__ int s_stk[2 * DG_IN_STACK];
@@ -822,7 +819,7 @@ __global__ __launch_bounds__(PF ? 128 : 64) __attribute__((amdgpu_waves_per_eu(8
             dgw_fail(g, DG_E_INTERNAL, lane);
             break;
         }
-        const bool skip_in = seg > 0 && u == c_start;     // the previous segment's worker merges in[u]
+        const bool skip_in = c_start != 0 && u == c_start; // the previous segment's worker merges in[u]
         const bool in_only = u == c_end;                  // ... which is this, for the next segment
         if (in_only && qh != qt) { dgw_fail(g, DG_E_INTERNAL, lane); break; }
 
@@ -1053,142 +1050,37 @@ __global__ __launch_bounds__(PF ? 128 : 64) __attribute__((amdgpu_waves_per_eu(8
     }
     if (PF && lane == 0) DG_PROG_SET(DG_PROG_DONE);
 #ifdef DG_STAMPS
-    if (t == 0 && seg == 0 && lane == 0) { p.st->dbg[0] = n_fast; p.st->dbg[1] = n_slow; p.st->dbg[2] = c_fast; p.st->dbg[3] = c_slow; p.st->dbg[4] = n_scalar; p.st->dbg[5] = c_a; p.st->dbg[6] = c_b; p.st->dbg[7] = c_c; p.st->dbg[8] = c_grp; p.st->dbg[9] = ng_in; p.st->dbg[10] = ng_out; p.st->dbg[11] = c_odd; p.st->dbg[12] = q_a; p.st->dbg[13] = q_b; p.st->dbg[14] = q_c; p.st->dbg[15] = q_d; }
+    if (t == 0 && c_start == 0 && lane == 0) { p.st->dbg[0] = n_fast; p.st->dbg[1] = n_slow; p.st->dbg[2] = c_fast; p.st->dbg[3] = c_slow; p.st->dbg[4] = n_scalar; p.st->dbg[5] = c_a; p.st->dbg[6] = c_b; p.st->dbg[7] = c_c; p.st->dbg[8] = c_grp; p.st->dbg[9] = ng_in; p.st->dbg[10] = ng_out; p.st->dbg[11] = c_odd; p.st->dbg[12] = q_a; p.st->dbg[13] = q_b; p.st->dbg[14] = q_c; p.st->dbg[15] = q_d; }
 #endif
 }
 
-// ============================================================================
-// Lane-per-segment mergeNodes.
-//
-// With full-span pileups about one backbone position in five is a cut vertex (0.96^40 at
-// 40x), so a target falls into hundreds of independent stretches of a few dozen vertices.
-// A wave per stretch spends a whole wave-instruction on work that occupies one to four lanes;
-// here every LANE sweeps a stretch of its own with the reference-literal single-lane
-// primitives (dgg_*), 64 stretches of one target per wave.  The exactness argument is the one
-// above k_cuts: a stretch between two cut vertices is swept in exactly the reference's FIFO
-// order and touches no state of any other stretch.
-//
-// row of p.cuts_ln: [0] = slots W, [1 + s] = first vertex of slot s (DG_NOCUT: the slot's
-// ideal range holds no cut vertex; its vertices belong to the slot in front).
-// ============================================================================
-#define DG_NOCUT 0xFFFFFFFFu
-
-__global__ __launch_bounds__(256) void k_cuts_fine(DgParams p) {
-    const uint32_t t = blockIdx.x;
+// mergeNodes (AlnGraphBoost.cpp:129-160): one wave per (target, segment of p.cuts)
+template <bool PF>
+__global__ __launch_bounds__(PF ? 128 : 64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_merge(DgParams p) {
+    const uint32_t t = blockIdx.x / p.seg_max, seg = blockIdx.x % p.seg_max;
     if (dg_failed(p) || dg_tskip(p, t)) return;
-    uint32_t *row = p.cuts_ln + (uint64_t)t * (p.ln_max + 2u);
-    const uint32_t blen = p.tlen[t];
-    const DgNode *nd = p.nodes + p.node_base[t];
-    const uint32_t *pool = p.pool + p.pool_base[t];
-    const uint32_t *bid = p.bid + p.bbv_base[t];
-    __shared__ int s_kg[4];
-    __shared__ uint32_t s_found[4];
-    // reads threaded into the graph = uses of enter's out-edges (AlnGraphBoost.cpp:60,106)
-    const DgNode en = nd[0];
-    int kg = 0;
-    for (int i = threadIdx.x; i < en.out_len; i += 256) kg += (int)pool[en.out_off + 2 * i + 1];
-    for (int o = 32; o; o >>= 1) kg += __shfl_xor(kg, o);
-    if ((threadIdx.x & 63) == 0) s_kg[threadIdx.x >> 6] = kg;
-    __syncthreads();
-    kg = s_kg[0] + s_kg[1] + s_kg[2] + s_kg[3];
-    uint32_t W = blen / (p.ln_space ? p.ln_space : 1u);
-    if (W > p.ln_max) W = p.ln_max;
-    if (W < 1) W = 1;
-    uint32_t found = 0;
-    for (uint32_t s = threadIdx.x; s < W; s += 256) {
-        uint32_t v = DG_NOCUT;
-        if (s == 0) v = 0;
-        else {
-            // slot s looks in [p0(s), p0(s+1)): disjoint ranges, so the cuts rise with s
-            const uint32_t p0 = 1u + (uint32_t)((uint64_t)s * blen / W);
-            const uint32_t p1 = 1u + (uint32_t)((uint64_t)(s + 1) * blen / W);
-            for (uint32_t pos = p0; pos < p1 && pos <= blen; pos++) {
-                const uint32_t x = bid[pos];
-                if (nd[x].weight - 1 == kg) { v = x; break; }
-            }
-        }
-        row[1 + s] = v;
-        found += v != DG_NOCUT;
-    }
-    for (int o = 32; o; o >>= 1) found += __shfl_xor(found, o);
-    if ((threadIdx.x & 63) == 0) s_found[threadIdx.x >> 6] = found;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        row[0] = W;
-        atomicAdd(&p.st->n_mseg, s_found[0] + s_found[1] + s_found[2] + s_found[3]);
-    }
+    const uint32_t *crow = p.cuts + (uint64_t)t * (p.seg_max + 2u);
+    const uint32_t nseg = crow[0];
+    if (seg >= nseg) return;
+    const int c_start = (int)crow[1 + seg];
+    const int c_end = seg + 1 < nseg ? (int)crow[2 + seg] : 0x7fffffff;     // the next segment's cut vertex
+    dg_merge_segment<PF>(p, t, c_start, c_end, p.stk + (uint64_t)blockIdx.x * p.stk_words);
 }
 
-__global__ __launch_bounds__(64) void k_merge_lanes(DgParams p) {
-    const uint32_t nblk = (p.ln_max + 63u) / 64u;
-    const uint32_t t = blockIdx.x / nblk;
-    if (dg_failed(p) || dg_tskip(p, t)) return;
-    const uint32_t *crow = p.cuts_ln + (uint64_t)t * (p.ln_max + 2u);
-    const uint32_t W = crow[0];
-    const uint32_t seg = (blockIdx.x % nblk) * 64u + threadIdx.x;
-    if (seg >= W) return;
-    const uint32_t cs = crow[1 + seg];
-    if (cs == DG_NOCUT) return;
-    uint32_t ce = DG_NOCUT;
-    for (uint32_t s = seg + 1; s < W && ce == DG_NOCUT; s++) ce = crow[1 + s];
-    const uint64_t nb = p.node_base[t];
-    const uint32_t NT = p.n_nodes[t];
-    const int c_start = (int)cs;
-    const int c_end = ce != DG_NOCUT ? (int)ce : 0x7fffffff;
-    const int c_hi = ce != DG_NOCUT ? c_end : (int)NT - 1;
-    DgGraph g;
-    g.nd = p.nodes + nb; g.queue = p.queue + nb + c_start;
-    g.pool = p.pool + p.pool_base[t]; g.pool_size = p.pool_size[t]; g.pool_top = p.pool_top + t;
-    g.stk = p.stk_ln + ((uint64_t)blockIdx.x * 64u + threadIdx.x) * p.stk_ln_words; g.stk_words = p.stk_ln_words;
-    g.st = p.st; g.tfail = p.tfail + t; g.t = t; g.err = false;
-    const uint32_t N = (uint32_t)(c_hi - c_start + 1);
-    uint32_t qh = 0, qt = 1;
-    g.queue[0] = c_start;
-    while (qh < qt && !g.err) {
-        const int u = g.queue[qh++];
-        if (u < c_start || u > c_hi) { dgg_fail(g, DG_E_INTERNAL); break; }
-        const bool skip_in = seg > 0 && u == c_start;     // the worker of the stretch in front merges in[u]
-        const bool in_only = u == c_end;                  // ... which is this, for the next stretch
-        if (in_only && qh != qt) { dgg_fail(g, DG_E_INTERNAL); break; }
-        uint4 h = dg_lo16(&g.nd[u]), h2 = dg_hi16(&g.nd[u]);
-        if (!skip_in) {
-            // mergeInNodes(u) can only find a group among >= 2 in-neighbours with one out-edge
-            const int n_in = DG_H_INLEN(h);
-            int nc = 0;
-            for (int i = 0; i < n_in; i++) {
-                const int s = (int)g.pool[DG_H2_INOFF(h2) + i];
-                nc += g.nd[s].out_len == 1;
-            }
-            if (nc >= 2) {
-                dgg_merge_in(g, u);
-                if (g.err) break;
-                h = dg_lo16(&g.nd[u]); h2 = dg_hi16(&g.nd[u]);
-            }
-        }
-        if (in_only) break;
-        {
-            const int n_out = DG_H_OUTLEN(h);
-            int nc = 0;
-            for (int i = 0; i < n_out; i++) {
-                const int d = (int)g.pool[DG_H2_OUTOFF(h2) + 2 * i];
-                nc += g.nd[d].in_len == 1;
-            }
-            if (nc >= 2) {
-                dgg_merge_out(g, u);
-                if (g.err) break;
-                h = dg_lo16(&g.nd[u]); h2 = dg_hi16(&g.nd[u]);
-            }
-        }
-        // AlnGraphBoost.cpp:143-158
-        const int n_out = DG_H_OUTLEN(h);
-        for (int i = 0; i < n_out; i++) {
-            const int d = (int)g.pool[DG_H2_OUTOFF(h2) + 2 * i];
-            const int pend = g.nd[d].pending - 1;
-            g.nd[d].pending = pend;
-            if (pend == 0) {
-                if (qt >= N) { dgg_fail(g, DG_E_INTERNAL); break; }
-                g.queue[qt++] = d;
-            }
-        }
+// the tiles k_merge_tile handed over (p.tile_list: [0] = entries, then (target, first vertex, last
+// vertex or DG_T_NONE) triples): one wave per entry, grid-stride
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_merge_list(DgParams p) {
+    if (dg_failed(p)) return;
+    const uint32_t n = p.tile_list[0] < p.tile_list_cap ? p.tile_list[0] : p.tile_list_cap;
+    for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
+        const uint32_t t = p.tile_list[4 + 3 * i];
+        if (dg_tskip(p, t)) continue;
+        const int c_start = (int)p.tile_list[5 + 3 * i];
+        const uint32_t ce = p.tile_list[6 + 3 * i];
+        dg_merge_segment<false>(p, t, c_start, ce == 0xFFFFFFFFu ? 0x7fffffff : (int)ce, p.stk + (uint64_t)blockIdx.x * p.stk_words);
+        if (threadIdx.x == 0) atomicAdd(&p.st->n_mseg, 1u);
+        DG_WAVE_FENCE();
     }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && p.tile_list[0] > p.tile_list_cap) dg_fail(p, DG_E_LIST_OVF);
 }
+
