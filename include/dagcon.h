@@ -191,6 +191,22 @@ int dagcon_normalize(dagcon_ctx *ctx, uint32_t n, const uint32_t *aln_start,
                      uint32_t *out_len, uint32_t *out_start);
 
 /*
+ * The `-a` stage (main.cpp:127-128, SimpleAligner.cpp:25-63): re-aligns n (query, target) pairs of
+ * UNALIGNED sequences, as the .pre format carries them (Alignment.cpp:82-112), on the device.
+ * Pair a is q_blob[q_off[a] .. +q_len[a]) against t_blob[t_off[a] .. +t_len[a]).  The aligned strings
+ * (equal lengths, '-' for gaps) are written to qaln / taln at out_off[a] (room for q_len[a] + t_len[a]
+ * columns each), their length to aln_len[a].  The alignment is global: in the terms of
+ * SimpleAligner.cpp:52-53 GenomicTBegin() = 0 and GenomicTEnd() = t_len[a]; the caller applies
+ * SimpleAligner.cpp:51-62 (start / end / reverse complement) itself.
+ * blasr_libcpp is not in the reference tree: this stage is pinned to the reference only by its one
+ * known-answer test (test/cpp/SimpleAlignerTest.cpp:8-21); everything else is parity-unpinned.
+ */
+int dagcon_align(dagcon_ctx *ctx, uint32_t n, const uint64_t *q_off, const uint32_t *q_len,
+                 const uint64_t *t_off, const uint32_t *t_len, const char *q_blob, uint64_t q_bytes,
+                 const char *t_blob, uint64_t t_bytes, const uint64_t *out_off, char *qaln, char *taln,
+                 uint32_t *aln_len);
+
+/*
  * Debug / parity aid: adjacency of one target's graph as left by the last
  * dagcon_run (after mergeNodes), in list order.  Vertex ids are in backbone
  * position order: the inserted vertices whose _bbMap is p (in read, column

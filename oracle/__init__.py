@@ -163,6 +163,63 @@ def parse_m5(line: bytes, group_by_target: bool = True):
     return out
 
 
+def parse_pre(line: bytes):
+    """Alignment.cpp:82-112 (restatement): dict with start as parsed (no +1) and end."""
+    L = lib()
+    p = Parsed()
+    end = C.c_uint32()
+    L.og_parse_pre.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(Parsed), C.POINTER(C.c_uint32)]
+    rc = L.og_parse_pre(line, len(line), C.byref(p), C.byref(end))
+    if rc != 1:
+        return None if rc == 0 else rc
+    out = dict(id=p.id, sid=p.sid, qstr=p.qstr, tstr=p.tstr, tlen=p.tlen, start=p.start, end=end.value,
+               strand=p.strand)
+    L.og_free_parsed(C.byref(p))
+    return out
+
+
+def ref_parse_pre(line: bytes):
+    """The reference's own parsePre (oracle/_ref)."""
+    R = ref_lib()
+    n = len(line) + 1
+    bufs = [C.create_string_buffer(n) for _ in range(4)]
+    tlen, start, end, strand = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.create_string_buffer(2)
+    R.ref_parse_pre(line, len(line), bufs[0], bufs[1], bufs[2], bufs[3], C.byref(tlen), C.byref(start),
+                    C.byref(end), strand)
+    return dict(id=bufs[0].value, sid=bufs[1].value, qstr=bufs[2].value, tstr=bufs[3].value,
+                tlen=tlen.value, start=start.value, end=end.value, strand=strand.raw[:1])
+
+
+def banded_align(q: bytes, t: bytes):
+    """The -a re-aligner's restatement (parity unpinned beyond SimpleAlignerTest.cpp:8-21): (qaln, taln)."""
+    L = lib()
+    L.og_banded_align.restype = C.c_size_t
+    L.og_banded_align.argtypes = [C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32, C.c_char_p, C.c_char_p]
+    qa, ta = C.create_string_buffer(len(q) + len(t) + 1), C.create_string_buffer(len(q) + len(t) + 1)
+    n = L.og_banded_align(q, len(q), t, len(t), qa, ta)
+    return qa.raw[:n], ta.raw[:n]
+
+
+def align_halfwidth(qlen: int, tlen: int) -> int:
+    L = lib()
+    L.og_align_halfwidth.restype = C.c_uint32
+    L.og_align_halfwidth.argtypes = [C.c_uint32, C.c_uint32]
+    return L.og_align_halfwidth(qlen, tlen)
+
+
+def simple_align(start: int, tlen: int, strand: bytes, qseq: bytes, tseq: bytes):
+    """SimpleAligner::align (SimpleAligner.cpp:25-63) on a parsePre record: (start, end, qstr, tstr)."""
+    L = lib()
+    qa, ta = banded_align(qseq, tseq)
+    qb, tb = C.create_string_buffer(qa, len(qa) + 1), C.create_string_buffer(ta, len(ta) + 1)
+    s, e = C.c_uint32(start), C.c_uint32(0)
+    L.og_simple_aligner_finish.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_char,
+                                           C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    L.og_simple_aligner_finish.restype = None
+    L.og_simple_aligner_finish(qb, tb, len(qa), len(tseq), tlen, strand[:1], C.byref(s), C.byref(e))
+    return s.value, e.value, qb.raw[:len(qa)], tb.raw[:len(ta)]
+
+
 def ref_parse_m5(line: bytes, group_by_target: bool = True):
     R = ref_lib()
     n = len(line) + 1

@@ -177,6 +177,130 @@ void og_free_parsed(og_parsed *p) {
     memset(p, 0, sizeof(*p));
 }
 
+/* Alignment.cpp:82-112 */
+int og_parse_pre(const char *line, size_t len, og_parsed *out, uint32_t *end_out) {
+    const char *f[16]; size_t fl[16]; int nf = 0;
+    size_t i = 0;
+    while (i <= len) {
+        size_t j = i;
+        while (j < len && line[j] != ' ') j++;
+        if (j > i && nf < 16) { f[nf] = line + i; fl[nf] = j - i; nf++; }
+        i = j + 1;
+    }
+    if (nf == 0) return 0;
+    if (nf < 8) return -1;
+    free(out->sid); free(out->id); free(out->qstr); free(out->tstr);
+    out->sid = dup_range(f[0], fl[0]);          /* :99 */
+    out->id = dup_range(f[1], fl[1]);           /* :100 */
+    out->strand = f[2][0];                      /* :101 */
+    out->tlen = parse_u32(f[3], fl[3]);         /* :103-104 */
+    out->start = parse_u32(f[4], fl[4]);        /* :106-107 (no +1 here: SimpleAligner.cpp:61 adds it) */
+    if (end_out) *end_out = parse_u32(f[5], fl[5]);   /* :109-110 */
+    out->qstr = dup_range(f[6], fl[6]);         /* :112 */
+    out->tstr = dup_range(f[7], fl[7]);
+    return 1;
+}
+
+/* ---- the -a re-aligner: see dagcon_oracle.h (parity unpinned beyond the reference's one KAT) ---- */
+static uint32_t isqrt_u64(uint64_t x) {
+    uint64_t r = 0, b = 1ull << 62;
+    while (b > x) b >>= 2;
+    while (b) {
+        if (x >= r + b) { x -= r + b; r = (r >> 1) + b; } else r >>= 1;
+        b >>= 2;
+    }
+    return (uint32_t)r;
+}
+
+uint32_t og_align_halfwidth(uint32_t qlen, uint32_t tlen) {
+    /* a random walk of indels at ~15 % leaves the scaled diagonal by ~sqrt(0.15 L); four of those, and room */
+    const uint64_t L = qlen > tlen ? qlen : tlen;
+    uint32_t w = 32u + 4u * isqrt_u64((15ull * L + 99ull) / 100ull);
+    if (w > 480u) w = 480u;                     /* band of at most 961 cells per row */
+    return w;
+}
+
+#define OG_AL_MATCH (-5)
+#define OG_AL_MISMATCH 6
+#define OG_AL_INS 4
+#define OG_AL_DEL 5
+#define OG_AL_INF (1 << 28)
+
+size_t og_banded_align(const char *q, uint32_t n, const char *t, uint32_t m, char *qaln, char *taln) {
+    if (n == 0 || m == 0) {
+        size_t k = 0;
+        for (uint32_t i = 0; i < n; i++) { qaln[k] = q[i]; taln[k] = '-'; k++; }
+        for (uint32_t j = 0; j < m; j++) { qaln[k] = '-'; taln[k] = t[j]; k++; }
+        qaln[k] = taln[k] = 0;
+        return k;
+    }
+    const uint32_t W = og_align_halfwidth(n, m), B = 2 * W + 1;
+    /* row i holds columns j = c_i - W + k, k = 0..B-1, c_i = i * m / n */
+    int32_t *prev = (int32_t *)malloc(sizeof(int32_t) * B), *cur = (int32_t *)malloc(sizeof(int32_t) * B);
+    uint8_t *dir = (uint8_t *)malloc((size_t)(n + 1) * B);
+    for (uint32_t i = 0; i <= n; i++) {
+        const int64_t ci = (int64_t)((uint64_t)i * m / n), cp = i ? (int64_t)((uint64_t)(i - 1) * m / n) : 0;
+        for (uint32_t k = 0; k < B; k++) {
+            const int64_t j = ci - (int64_t)W + k;
+            int32_t best = OG_AL_INF; uint8_t d = 3;
+            if (j >= 0 && j <= (int64_t)m) {
+                if (i == 0 && j == 0) { best = 0; d = 3; }
+                if (i > 0 && j > 0) {                       /* diagonal: (i-1, j-1) */
+                    const int64_t kp = j - 1 - (cp - (int64_t)W);
+                    if (kp >= 0 && kp < (int64_t)B && prev[kp] < OG_AL_INF) {
+                        const int32_t v = prev[kp] + (q[i - 1] == t[j - 1] ? OG_AL_MATCH : OG_AL_MISMATCH);
+                        if (v < best) { best = v; d = 0; }
+                    }
+                }
+                if (i > 0) {                                /* insertion: (i-1, j), gap in the target */
+                    const int64_t kp = j - (cp - (int64_t)W);
+                    if (kp >= 0 && kp < (int64_t)B && prev[kp] < OG_AL_INF) {
+                        const int32_t v = prev[kp] + OG_AL_INS;
+                        if (v < best) { best = v; d = 1; }
+                    }
+                }
+                if (j > 0 && k > 0 && cur[k - 1] < OG_AL_INF) {    /* deletion: (i, j-1), gap in the query */
+                    const int32_t v = cur[k - 1] + OG_AL_DEL;
+                    if (v < best) { best = v; d = 2; }
+                }
+            }
+            cur[k] = best;
+            dir[(size_t)i * B + k] = d;
+        }
+        int32_t *x = prev; prev = cur; cur = x;
+    }
+    /* traceback from (n, m) */
+    size_t len = 0;
+    char *rq = (char *)malloc((size_t)n + m + 1), *rt = (char *)malloc((size_t)n + m + 1);
+    uint32_t i = n, j = m;
+    while (i > 0 || j > 0) {
+        const int64_t ci = (int64_t)((uint64_t)i * m / n);
+        const uint8_t d = dir[(size_t)i * B + (size_t)((int64_t)j - (ci - (int64_t)W))];
+        if (d == 0) { rq[len] = q[--i]; rt[len] = t[--j]; }
+        else if (d == 1) { rq[len] = q[--i]; rt[len] = '-'; }
+        else if (d == 2) { rq[len] = '-'; rt[len] = t[--j]; }
+        else break;                                   /* cannot happen: (0,0) is inside the band */
+        len++;
+    }
+    for (size_t k = 0; k < len; k++) { qaln[k] = rq[len - 1 - k]; taln[k] = rt[len - 1 - k]; }
+    qaln[len] = taln[len] = 0;
+    free(prev); free(cur); free(dir); free(rq); free(rt);
+    return len;
+}
+
+/* SimpleAligner.cpp:51-62 */
+void og_simple_aligner_finish(char *qaln, char *taln, size_t n, uint32_t tseq_len, uint32_t tlen,
+                              char strand, uint32_t *start, uint32_t *end) {
+    *start += 0;                                /* :52  refinedAln.GenomicTBegin(): the global alignment starts at 0 */
+    *end = *start + tseq_len;                   /* :53  + GenomicTEnd() */
+    if (strand == '-') {
+        *start = tlen - *end;                   /* :56 */
+        og_revcomp(qaln, n);                    /* :57-58 */
+        og_revcomp(taln, n);
+    }
+    *start += 1;                                /* :62 */
+}
+
 /* ------------------------------------------------------------------------ */
 /* AlnGraphBoost                                                            */
 /* ------------------------------------------------------------------------ */

@@ -53,6 +53,28 @@ typedef struct og_parsed {
 int og_parse_m5(const char *line, size_t len, int group_by_target, og_parsed *out);
 void og_free_parsed(og_parsed *p);
 
+/* Alignment.cpp:82-112 parsePre: "qid tid strand tlen tstart tend qseq tseq" (the two sequences
+ * are UNALIGNED substrings; main.cpp:243-246 selects this parser together with -a).  `end` goes to
+ * *end_out.  Returns 0 on an empty line, -1 on fewer than 8 fields (the reference indexes
+ * fields[7]: undefined behaviour), 1 otherwise. */
+int og_parse_pre(const char *line, size_t len, og_parsed *out, uint32_t *end_out);
+
+/* ---- the -a re-aligner (SimpleAligner.cpp:25-63) ------------------------
+ * blasr_libcpp (SDPAlign + GuidedAlign) is not in the tree: PARITY UNPINNED except for the
+ * reference's one known-answer test (test/cpp/SimpleAlignerTest.cpp:8-21), which this restatement
+ * reproduces: a global alignment that minimises blasr's distance score (SimpleAligner.cpp:10-23:
+ * match -5, mismatch +6 from SMRTDistanceMatrix, insertion 4, deletion 5), ties resolved
+ * diagonal first, then insertion (gap in the target), then deletion, inside a band of half-width
+ * og_align_halfwidth(qlen, tlen) around the length-scaled diagonal j = i * tlen / qlen.
+ * Outputs (capacity qlen + tlen + 1 each) get the aligned strings; returns their length. */
+uint32_t og_align_halfwidth(uint32_t qlen, uint32_t tlen);
+size_t og_banded_align(const char *q, uint32_t qlen, const char *t, uint32_t tlen, char *qaln, char *taln);
+/* SimpleAligner.cpp:51-62: what align() does to start / end / strings once the aligner has
+ * produced (queryStr, targetStr, GenomicTBegin = 0, GenomicTEnd = tlen of the record's tstr).
+ * qaln / taln are rewritten in place (reverse-complemented for the '-' strand). */
+void og_simple_aligner_finish(char *qaln, char *taln, size_t n, uint32_t tseq_len, uint32_t tlen,
+                              char strand, uint32_t *start, uint32_t *end);
+
 /* ---- AlnGraphBoost.cpp ------------------------------------------------ */
 
 typedef struct og_graph og_graph;

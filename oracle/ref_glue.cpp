@@ -65,6 +65,25 @@ int ref_parse_m5(const char* line, size_t len, int group_by_target,
     return 1;
 }
 
+// parsePre (Alignment.cpp:82-112) through operator>> on one line.
+int ref_parse_pre(const char* line, size_t len, char* id, char* sid, char* qstr, char* tstr,
+                  uint32_t* tlen, uint32_t* start, uint32_t* end, char* strand) {
+    dagcon::Alignment::parse = parsePre;
+    std::istringstream in(std::string(line, len));
+    dagcon::Alignment a;
+    in >> a;
+    dagcon::Alignment::parse = parseM5;
+    std::strcpy(id, a.id.c_str());
+    std::strcpy(sid, a.sid.c_str());
+    std::strcpy(qstr, a.qstr.c_str());
+    std::strcpy(tstr, a.tstr.c_str());
+    *tlen = a.tlen;
+    *start = a.start;
+    *end = a.end;
+    *strand = a.strand;
+    return 1;
+}
+
 // revComp (Alignment.cpp:15-26).  In place.
 void ref_revcomp(char* seq, size_t len) {
     std::string s(seq, len);

@@ -29,7 +29,7 @@ EXPORTS = [
     "dagcon_abi_version", "dagcon_default_opts", "dagcon_create", "dagcon_destroy",
     "dagcon_last_error", "dagcon_consensus", "dagcon_upload", "dagcon_run", "dagcon_sync",
     "dagcon_fetch", "dagcon_get_timings", "dagcon_normalize", "dagcon_debug_graph",
-    "dagcon_debug_counters", "dagcon_host_alloc", "dagcon_host_free",
+    "dagcon_debug_counters", "dagcon_host_alloc", "dagcon_host_free", "dagcon_align",
 ]
 ABI_VERSION = 2
 
@@ -109,6 +109,7 @@ def load() -> C.CDLL:
     L.dagcon_normalize.argtypes = [vp, C.c_uint32, vp, vp, vp, vp, vp, C.c_uint64, C.c_uint32,
                                    C.c_uint32, vp, vp, vp, vp, vp]
     L.dagcon_debug_graph.argtypes = [vp, C.c_uint32, C.POINTER(GraphDump)]
+    L.dagcon_align.argtypes = [vp, C.c_uint32, vp, vp, vp, vp, vp, C.c_uint64, vp, C.c_uint64, vp, vp, vp, vp]
     L.dagcon_host_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
     L.dagcon_host_free.argtypes = [vp, vp]
     L.dagcon_host_free.restype = None
@@ -319,6 +320,28 @@ class Context:
             o, m = int(out_off[a]), int(out_len[a])
             res.append((int(out_start[a]), qout[o:o + m].tobytes(), tout[o:o + m].tobytes()))
         return res
+
+    def align(self, pairs):
+        """pairs = [(qseq, tseq)] of unaligned sequences -> [(qaln, taln)] (the -a stage, SimpleAligner.cpp:25-63)."""
+        n = len(pairs)
+        if n == 0:
+            return []
+        ql = np.array([len(q) for q, _ in pairs], dtype=np.uint32)
+        tl = np.array([len(t) for _, t in pairs], dtype=np.uint32)
+        qo, to, oo = np.zeros(n, np.uint64), np.zeros(n, np.uint64), np.zeros(n, np.uint64)
+        qo[1:] = np.cumsum(ql[:-1], dtype=np.uint64)
+        to[1:] = np.cumsum(tl[:-1], dtype=np.uint64)
+        oo[1:] = np.cumsum((ql[:-1].astype(np.uint64) + tl[:-1]), dtype=np.uint64)
+        qb = np.frombuffer(b"".join(q for q, _ in pairs) or b"\0", dtype=np.uint8)
+        tb = np.frombuffer(b"".join(t for _, t in pairs) or b"\0", dtype=np.uint8)
+        total = int(ql.sum()) + int(tl.sum()) + 1
+        qa, ta = np.zeros(total, np.uint8), np.zeros(total, np.uint8)
+        ln = np.zeros(n, np.uint32)
+        self._chk(self.L.dagcon_align(self.h, n, qo.ctypes.data, ql.ctypes.data, to.ctypes.data, tl.ctypes.data,
+                                      qb.ctypes.data, int(ql.sum()), tb.ctypes.data, int(tl.sum()), oo.ctypes.data,
+                                      qa.ctypes.data, ta.ctypes.data, ln.ctypes.data))
+        return [(qa[int(oo[a]):int(oo[a]) + int(ln[a])].tobytes(), ta[int(oo[a]):int(oo[a]) + int(ln[a])].tobytes())
+                for a in range(n)]
 
     def debug_counters(self):
         a = (C.c_ulonglong * 16)()

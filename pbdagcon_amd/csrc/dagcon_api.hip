@@ -20,6 +20,7 @@
 #include "k_merge.hip.h"
 #include "k_merge_tile.hip.h"
 #include "k_bestpath.hip.h"
+#include "k_align.hip.h"
 
 namespace {
 
@@ -64,6 +65,7 @@ struct Ctx {
     DevBuf d_matA, d_matD, d_matC, d_cov, d_gcount, d_gbase, d_bid;
     DevBuf d_nodes, d_best, d_queue, d_score, d_cns_tmp, d_bp_tt;
     DevBuf d_pool, d_stk, d_cuts, d_cuts_bp, d_bp_stat, d_bp_len, d_nextcut, d_tile_list;
+    DevBuf d_al[12];                                // dagcon_align: blobs, offsets, outputs, directions
     DevBuf d_cns, d_cns_off, d_cns_len, d_seg_first, d_n_seg, d_seg_r0, d_seg_r1, d_st;
 
     uint64_t norm_cap = 0, node_cap = 0, pool_cap = 0, cns_cap = 0, seg_cap = 0;
@@ -355,6 +357,7 @@ void dagcon_destroy(dagcon_ctx *ctx) {
                      &c->d_cns_off, &c->d_cns_len, &c->d_seg_first, &c->d_n_seg, &c->d_seg_r0, &c->d_seg_r1,
                      &c->d_st};
     for (DevBuf *b : all) free_buf(*b);
+    for (DevBuf &b : c->d_al) free_buf(b);
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -814,6 +817,79 @@ int dagcon_normalize(dagcon_ctx *ctx, uint32_t n, const uint32_t *aln_start, con
     c->opts = saved;
     c->uploaded = false; c->ran = false;
     return r;
+}
+
+int dagcon_align(dagcon_ctx *ctx, uint32_t n, const uint64_t *q_off, const uint32_t *q_len,
+                 const uint64_t *t_off, const uint32_t *t_len, const char *q_blob, uint64_t q_bytes,
+                 const char *t_blob, uint64_t t_bytes, const uint64_t *out_off, char *qaln, char *taln,
+                 uint32_t *aln_len) {
+    if (!ctx) return DAGCON_ERR_INVALID_ARG;
+    Ctx *c = reinterpret_cast<Ctx *>(ctx);
+    if (n == 0) return DAGCON_OK;
+    if (!q_off || !q_len || !t_off || !t_len || !q_blob || !t_blob || !out_off || !qaln || !taln || !aln_len)
+        return fail(c, DAGCON_ERR_INVALID_ARG, "NULL argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    uint64_t out_bytes = 0;
+    std::vector<uint64_t> dir_off(n);
+    for (uint32_t a = 0; a < n; a++) {
+        if (q_off[a] > q_bytes || q_len[a] > q_bytes - q_off[a] || t_off[a] > t_bytes || t_len[a] > t_bytes - t_off[a])
+            return fail(c, DAGCON_ERR_INVALID_ARG, "pair %u runs past its blob", a);
+        if ((uint64_t)q_len[a] + t_len[a] > 0x7FFFFFF0ull) return fail(c, DAGCON_ERR_UNSUPPORTED, "pair %u too long", a);
+        out_bytes = std::max<uint64_t>(out_bytes, out_off[a] + (uint64_t)q_len[a] + t_len[a]);
+    }
+    DevBuf &dq = c->d_al[0], &dt = c->d_al[1], &dqo = c->d_al[2], &dto = c->d_al[3], &dql = c->d_al[4], &dtl = c->d_al[5],
+           &doo = c->d_al[6], &dqa = c->d_al[7], &dta = c->d_al[8], &dlen = c->d_al[9], &ddir = c->d_al[10], &ddo = c->d_al[11];
+    ENSURE(c, dq, q_bytes); ENSURE(c, dt, t_bytes);
+    ENSURE(c, dqo, (size_t)n * 8); ENSURE(c, dto, (size_t)n * 8); ENSURE(c, dql, (size_t)n * 4); ENSURE(c, dtl, (size_t)n * 4);
+    ENSURE(c, doo, (size_t)n * 8); ENSURE(c, dqa, out_bytes); ENSURE(c, dta, out_bytes); ENSURE(c, dlen, (size_t)n * 4);
+    ENSURE(c, ddo, (size_t)n * 8);
+    hipStream_t s = c->stream;
+    HIPCHK(c, hipMemcpyAsync(dq.p, q_blob, q_bytes, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(dt.p, t_blob, t_bytes, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(dqo.p, q_off, (size_t)n * 8, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(dto.p, t_off, (size_t)n * 8, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(dql.p, q_len, (size_t)n * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(dtl.p, t_len, (size_t)n * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(doo.p, out_off, (size_t)n * 8, hipMemcpyHostToDevice, s));
+    // direction words (64 per row, q_len + 1 rows per pair) for as many pairs at a time as fit the budget
+    uint64_t budget_rows = (6ull << 30) / 256ull;
+    if (const char *e = getenv("DAGCON_ALIGN_ROWS")) { const long long v = atoll(e); if (v >= 1) budget_rows = (uint64_t)v; }   // test knob
+    uint32_t first = 0;
+    while (first < n) {
+        uint64_t rows = 0;
+        uint32_t cnt = 0;
+        while (first + cnt < n) {
+            const uint64_t r = (uint64_t)q_len[first + cnt] + 1;
+            if (cnt && rows + r > budget_rows) break;
+            dir_off[first + cnt] = rows;
+            rows += r; cnt++;
+        }
+        ENSURE(c, ddir, rows * 256ull);
+        HIPCHK(c, hipMemcpyAsync((uint64_t *)ddo.p + first, dir_off.data() + first, (size_t)cnt * 8, hipMemcpyHostToDevice, s));
+        DgAlignParams ap;
+        ap.q = (const uint8_t *)dq.p; ap.t = (const uint8_t *)dt.p;
+        ap.q_off = (const uint64_t *)dqo.p; ap.t_off = (const uint64_t *)dto.p;
+        ap.q_len = (const uint32_t *)dql.p; ap.t_len = (const uint32_t *)dtl.p;
+        ap.out_off = (const uint64_t *)doo.p; ap.qaln = (uint8_t *)dqa.p; ap.taln = (uint8_t *)dta.p;
+        ap.aln_len = (uint32_t *)dlen.p; ap.dirs = (uint32_t *)ddir.p; ap.dir_off = (const uint64_t *)ddo.p;
+        ap.first = first; ap.n = cnt;
+        hipLaunchKernelGGL(k_align_banded, dim3(cnt), dim3(64), 0, s, ap);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipStreamSynchronize(s));       // (the direction buffer is reused by the next group)
+        first += cnt;
+    }
+    HIPCHK(c, hipMemcpy(aln_len, dlen.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(qaln, dqa.p, out_bytes, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(taln, dta.p, out_bytes, hipMemcpyDeviceToHost));
+    // the kernel fills each pair's room from the back (it walks the alignment from its end)
+    for (uint32_t a = 0; a < n; a++) {
+        const uint64_t cap = (uint64_t)q_len[a] + t_len[a], len = aln_len[a];
+        if (len > cap) return fail(c, DAGCON_ERR_INTERNAL, "pair %u: alignment longer than its room", a);
+        if (q_len[a] == 0 || t_len[a] == 0) continue;    // (written from the front)
+        memmove(qaln + out_off[a], qaln + out_off[a] + (cap - len), len);
+        memmove(taln + out_off[a], taln + out_off[a] + (cap - len), len);
+    }
+    return DAGCON_OK;
 }
 
 int dagcon_host_alloc(dagcon_ctx *ctx, size_t bytes, void **out) {

@@ -13,7 +13,9 @@
 //   * output order is input order (the reference's is nondeterministic for -j >= 2, Q3);
 //   * -j is the number of host threads that index the text and copy the strings (the consensus
 //     itself is the GPU's), -j 1 does not deadlock (Q2);
-//   * -a (re-align .pre input through blasr_libcpp) is refused: that library is absent;
+//   * -a (.pre input, every record re-aligned first: main.cpp:127-128, 243-246) runs this build's own
+//     banded aligner on the GPU (dagcon_align): blasr_libcpp is absent, the stage is pinned to the
+//     reference by its one known-answer test only (test/cpp/SimpleAlignerTest.cpp:8-21);
 //   * blank lines are skipped (the reference duplicates the previous record, Q9);
 //   * a missing input file is an error on stderr, exit 1 (the reference is silent, Q11).
 #include <algorithm>
@@ -57,11 +59,11 @@ void usage(FILE *f) {
             "  -c, --min-coverage  minimum alignments per target, also the minimum node weight (default 6)\n"
             "  -m, --min-length    minimum alignment / consensus length (default 500)\n"
             "  -t, --trim          trim alignments on either side (default 50)\n"
-            "  -a, --align         not available in this build (needs blasr_libcpp)\n"
+            "  -a, --align         input is .pre (qid tid strand tlen tstart tend qseq tseq): align the sequences first\n"
             "  -v, --verbose       per-target progress on stderr\n"
             "  --devices LIST      GPUs to use, e.g. 0,1,2,3 (default 0): one consensus worker per GPU, batches of\n"
             "                      targets dealt round-robin, records still printed in input order\n"
-            "  <input>             BLASR -m 5 file sorted by target, or - for stdin\n"
+            "  <input>             BLASR -m 5 file (.pre with -a) sorted by target, or - for stdin\n"
             "  version 0.3 (dagcon-mi355x)\n");
 }
 
@@ -169,12 +171,13 @@ struct Blob {
 
 struct Batch {
     std::vector<std::string> ids;
-    std::vector<uint32_t> tlen, start, len;
-    std::vector<uint64_t> begin{0}, off;
+    std::vector<uint32_t> tlen, start, len, len2;          // len2 / off2: the target sequence of a .pre record
+    std::vector<uint64_t> begin{0}, off, off2;
+    std::vector<char> strand;
     Blob q, t;
     unsigned long long seq = 0;        // position in the input: records are printed in this order
     std::string out;                   // the batch's FASTA records
-    void clear() { ids.clear(); tlen.clear(); start.clear(); len.clear(); begin.assign(1, 0); off.clear(); q.n = 0; t.n = 0; out.clear(); }
+    void clear() { ids.clear(); tlen.clear(); start.clear(); len.clear(); len2.clear(); begin.assign(1, 0); off.clear(); off2.clear(); strand.clear(); q.n = 0; t.n = 0; out.clear(); }
 };
 
 // one batch through the device; the records go to b.out (main.cpp:141-143), warnings to stderr
@@ -187,6 +190,39 @@ int flush(dagcon_ctx *ctx, Batch &b, const Opts &o) {
     db.tlen = b.tlen.data(); db.aln_begin = b.begin.data();
     db.aln_start = b.start.data(); db.aln_off = b.off.data(); db.aln_len = b.len.data();
     db.qstr = b.q.data(); db.tstr = b.t.data(); db.blob_bytes = b.q.size();
+    // -a: SimpleAligner on every record first (main.cpp:127-128)
+    std::vector<uint64_t> ooff;
+    std::vector<uint32_t> alen, nstart;
+    std::string qa, ta;
+    if (o.align) {
+        const size_t A = b.start.size();
+        ooff.resize(A); alen.assign(A, 0); nstart.resize(A);
+        uint64_t tot = 0;
+        for (size_t a = 0; a < A; a++) { ooff[a] = tot; tot += (uint64_t)b.len[a] + b.len2[a]; }
+        qa.resize(tot + 1); ta.resize(tot + 1);
+        int rc = dagcon_align(ctx, (uint32_t)A, b.off.data(), b.len.data(), b.off2.data(), b.len2.data(), b.q.data(), b.q.size(),
+                              b.t.data(), b.t.size(), ooff.data(), &qa[0], &ta[0], alen.data());
+        if (rc != DAGCON_OK) {
+            fprintf(stderr, "pbdagcon: alignment failed (%d): %s\n", rc, dagcon_last_error(ctx));
+            return 1;
+        }
+        size_t g = 0;
+        for (size_t a = 0; a < A; a++) {
+            while (b.begin[g + 1] <= a) g++;
+            // SimpleAligner.cpp:51-62 (the alignment is global: GenomicTBegin() = 0, GenomicTEnd() = |tseq|)
+            uint32_t start = b.start[a];
+            const uint32_t end = start + b.len2[a];
+            if (b.strand[a] == '-') {
+                start = b.tlen[g] - end;
+                std::string tmp(alen[a], 0);
+                revcomp_into(&tmp[0], &qa[ooff[a]], alen[a]); memcpy(&qa[ooff[a]], tmp.data(), alen[a]);
+                revcomp_into(&tmp[0], &ta[ooff[a]], alen[a]); memcpy(&ta[ooff[a]], tmp.data(), alen[a]);
+            }
+            nstart[a] = start + 1;
+        }
+        db.aln_start = nstart.data(); db.aln_off = ooff.data(); db.aln_len = alen.data();
+        db.qstr = qa.data(); db.tstr = ta.data(); db.blob_bytes = tot;
+    }
     dagcon_results r;
     int rc = dagcon_consensus(ctx, &db, &r);
     if (rc != DAGCON_OK) {
@@ -221,11 +257,6 @@ int flush(dagcon_ctx *ctx, Batch &b, const Opts &o) {
 int main(int argc, char **argv) {
     Opts o;
     if (int rc = parse_args(argc, argv, o)) return rc;
-    if (o.align) {
-        fprintf(stderr, "pbdagcon: -a/--align needs blasr_libcpp (SimpleAligner.cpp), which this build does not have;\n"
-                        "          give it aligned -m 5 input instead\n");
-        return 2;
-    }
     // ---- input: mmap a file, or slurp stdin ----
     const char *data = nullptr;
     size_t size = 0;
@@ -353,7 +384,7 @@ int main(int argc, char **argv) {
     // 3. per batch the same threads copy (or reverse-complement) the strings into the blobs.
     struct Rec {
         const char *id, *name, *q, *t;
-        uint32_t idl, namel, len, tlen, start;
+        uint32_t idl, namel, len, tlen, start, tl;   // tl: length of the target sequence (.pre); len: of the query string
         char strand;
     };
     struct Part { std::vector<Rec> recs; int err = 0; unsigned long long err_rec = 0; int err_nf = 0; };
@@ -404,12 +435,26 @@ int main(int argc, char **argv) {
                     i = j;
                 }
                 if (nf == 0) continue;                          // blank line
+                if (o.align) {
+                    // Alignment.cpp:82-112 parsePre: qid tid strand tlen tstart tend qseq tseq
+                    if (nf < 8) { pt.err = 1; pt.err_rec = pt.recs.size() + 1; pt.err_nf = nf; return; }
+                    Rec r;
+                    r.id = f[1]; r.idl = (uint32_t)fl[1];
+                    r.name = f[0]; r.namel = (uint32_t)fl[0];
+                    r.strand = f[2][0];
+                    r.tlen = tok_u32(f[3], fl[3]);
+                    r.start = tok_u32(f[4], fl[4]);             // (SimpleAligner.cpp:61 adds the 1)
+                    r.q = f[6]; r.len = (uint32_t)fl[6];
+                    r.t = f[7]; r.tl = (uint32_t)fl[7];
+                    pt.recs.push_back(r);
+                    continue;
+                }
                 if (nf < 19) { pt.err = 1; pt.err_rec = pt.recs.size() + 1; pt.err_nf = nf; return; }
                 if (fl[16] != fl[18]) { pt.err = 2; pt.err_rec = pt.recs.size() + 1; return; }
                 Rec r;
                 r.id = f[5]; r.idl = (uint32_t)fl[5];
                 r.name = f[0]; r.namel = (uint32_t)fl[0];
-                r.q = f[16]; r.t = f[18]; r.len = (uint32_t)fl[16];
+                r.q = f[16]; r.t = f[18]; r.len = (uint32_t)fl[16]; r.tl = r.len;
                 r.tlen = tok_u32(f[6], fl[6]);
                 r.start = tok_u32(f[7], fl[7]) + 1;             // Alignment.cpp:65-66
                 r.strand = f[9][0];
@@ -427,7 +472,7 @@ int main(int argc, char **argv) {
             for (const Rec &r : parts[k].recs) recs.push_back(&r);
             n_rec_before += parts[k].recs.size();
             if (parts[k].err == 1) {
-                fprintf(stderr, "pbdagcon: format error: record %llu has %d fields, 19 expected\n", n_rec_before + 1, parts[k].err_nf);
+                fprintf(stderr, "pbdagcon: format error: record %llu has %d fields, %d expected\n", n_rec_before + 1, parts[k].err_nf, o.align ? 8 : 19);
                 had_error = true; break;
             }
             if (parts[k].err == 2) {
@@ -437,15 +482,18 @@ int main(int argc, char **argv) {
         }
     };
     // copies the strings of records [r0, r1) into batch b, whose offsets are set already
-    auto fill_strings = [&](Batch &b, size_t r0, size_t r1, size_t bytes) {
+    auto fill_strings = [&](Batch &b, size_t r0, size_t r1, size_t bytes, size_t bytes2) {
         dagcon_ctx *pin = nullptr;
         if (want_pin) { std::lock_guard<std::mutex> lk(mu); pin = pin_ctx; }
-        if (!b.q.resize(bytes, pin) || !b.t.resize(bytes, pin)) { fprintf(stderr, "pbdagcon: out of memory\n"); exit(1); }
+        if (!b.q.resize(bytes, pin) || !b.t.resize(bytes2, pin)) { fprintf(stderr, "pbdagcon: out of memory\n"); exit(1); }
         auto work = [&](unsigned k) {
             for (size_t x = r0 + k; x < r1; x += nthr) {
                 const Rec &r = *recs[x];
-                char *dq = b.q.data() + b.off[x - r0], *dt = b.t.data() + b.off[x - r0];
-                if (r.strand == '-') {                            // Alignment.cpp:69-75: start is NOT flipped (Q6)
+                char *dq = b.q.data() + b.off[x - r0], *dt = b.t.data() + b.off2[x - r0];
+                if (o.align) {                                    // .pre: sequences as they are (Alignment.cpp:112)
+                    memcpy(dq, r.q, r.len);
+                    memcpy(dt, r.t, r.tl);
+                } else if (r.strand == '-') {                            // Alignment.cpp:69-75: start is NOT flipped (Q6)
                     revcomp_into(dq, r.q, r.len);
                     revcomp_into(dt, r.t, r.len);
                 } else {
@@ -479,7 +527,7 @@ int main(int argc, char **argv) {
                    memcmp(recs[n_use - 1]->id, recs.back()->id, recs.back()->idl) == 0) n_use--;
         }
         size_t rb = 0;                                   // first record of the batch being formed
-        size_t bytes = 0;
+        size_t bytes = 0, bytes2 = 0;
         for (size_t x = 0; x <= n_use && status == 0; x++) {
             const bool last = x == n_use;
             const bool new_target = !last && (x == rb || recs[x]->idl != recs[x - 1]->idl ||
@@ -489,7 +537,7 @@ int main(int argc, char **argv) {
             if (last || (new_target && x > rb && (b.ids.size() >= o.batch_targets || bytes >= o.batch_bytes))) {
                 if (x > rb) {
                     b.begin.push_back(b.start.size());
-                    fill_strings(b, rb, x, bytes);
+                    fill_strings(b, rb, x, bytes, bytes2);
                     if (o.dump) {
                         for (size_t y = rb; y < x; y++) {
                             const Rec &r = *recs[y];
@@ -497,12 +545,12 @@ int main(int argc, char **argv) {
                             size_t g = 0;
                             while (b.begin[g + 1] <= y - rb) g++;
                             printf("%.*s\t%u\t%u\t%c\t%.*s\t%.*s\t%.*s\n", (int)r.idl, r.id, b.tlen[g], r.start, r.strand,
-                                   (int)r.namel, r.name, (int)r.len, b.q.data() + o0, (int)r.len, b.t.data() + o0);
+                                   (int)r.namel, r.name, (int)r.len, b.q.data() + o0, (int)r.tl, b.t.data() + b.off2[y - rb]);
                         }
                         b.clear();
                     } else status = submit();
                 }
-                rb = x; bytes = 0;
+                rb = x; bytes = 0; bytes2 = 0;
                 if (last || status) break;
             }
             const Rec &r = *recs[x];
@@ -512,9 +560,10 @@ int main(int argc, char **argv) {
                 b.tlen.push_back(r.tlen);
             }
             b.start.push_back(r.start);
-            b.off.push_back(bytes);
-            b.len.push_back(r.len);
-            bytes += r.len;
+            b.off.push_back(bytes); b.off2.push_back(bytes2);
+            b.len.push_back(r.len); b.len2.push_back(r.tl);
+            b.strand.push_back(r.strand);
+            bytes += r.len; bytes2 += r.tl;
         }
         // the unfinished target's records wait for the next slab
         std::vector<Rec> next_carry;

@@ -72,6 +72,21 @@ def main():
     json.dump(dict(source="reference Alignment.cpp via oracle/_ref/libref_alignment.so",
                    vectors=vec, parsed=parsed), open(os.path.join(HERE, "a1_vectors.json"), "w"), indent=0)
 
+    # .pre lines (Alignment.cpp:82-112 parsePre) through the reference's own parser
+    pre = []
+    for i in range(40):
+        n, m = int(rng.integers(1, 60)), int(rng.integers(1, 60))
+        q = bytes(b"ACGT"[j] for j in rng.integers(0, 4, n)).decode()
+        t = bytes(b"ACGTN"[j] for j in rng.integers(0, 5, m)).decode()
+        tlen = int(rng.integers(m, 5000))
+        ts = int(rng.integers(0, tlen - m + 1))
+        sep = " " if i % 5 else "  "                 # empty fields are skipped (Alignment.cpp:89-92)
+        line = sep.join([f"q{i}/0_{n}", f"t{i % 7}", "+-"[i % 2], str(tlen), str(ts), str(ts + m), q, t])
+        r = oracle.ref_parse_pre(line.encode())
+        pre.append(dict(line=line, **{k: (v.decode() if isinstance(v, bytes) else v) for k, v in r.items()}))
+    json.dump(dict(source="reference Alignment.cpp parsePre via oracle/_ref/libref_alignment.so", parsed=pre),
+              open(os.path.join(HERE, "pre_vectors.json"), "w"), indent=0)
+
     kat = dict(
         raw_consensus=dict(backbone="ATATTAGGC", start=1, expected="ATATAGCCGGC", alignments=[
             dict(t="ATATTA---GGC", q="ATAT-AGCCGGC"), dict(t="ATATTA-GGC", q="ATAT-ACGGC"),
@@ -86,8 +101,13 @@ def main():
             dict(trim=0, start=1, t="ACG-TCA-GCA", q="AC-C-C-T---"),
             dict(trim=3, start=4, t="-TCA-", q="C-C-T"), dict(trim=4, start=5, t="C", q="C"),
             dict(trim=5, start=6, t="", q=""), dict(trim=500, start=None, t="", q="")]),
+        simple_aligner=dict(start=765, end=826, tlen=2092, strand="-",
+                            tstr="ACAGAGATGCAAGGTAAAGTACAATTGAAAAACTAACCTCTTCCAGCGAGACTTATAGCGA",
+                            qstr="ACAGAAGATGAAGGTAAATACAATGAAAAAACTACCTCGGTTCCAGCGAGAACTATAGCGA",
+                            expected_tstr="TCGCTATAAGT-CTCGCTGGAA--GAGGTTAGTTTTT-CAATTGTACTTTACCTTGCATCT-CTGT",
+                            expected_start=1267),
         source="test/cpp/AlnGraphBoostTest.cpp:11-57, test/cpp/AlignmentTest.cpp:19-143, "
-               "src/tests/test_aligngraph.py:50-54")
+               "test/cpp/SimpleAlignerTest.cpp:8-21, src/tests/test_aligngraph.py:50-54")
     json.dump(kat, open(os.path.join(HERE, "kat_graph.json"), "w"), indent=1)
 
     from pbdagcon_amd import synth

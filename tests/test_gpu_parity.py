@@ -714,3 +714,82 @@ def test_bench_two_ranks_share_the_gpu():
     line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["fasta_gather_ok"] is True and line["bit_exact_vs_oracle"] is True
     assert line["targets_verified"] == 24 + 16
+
+
+# ---- the -a stage: .pre records re-aligned on the device ------------------------
+
+def _mutate(rng, t, sub=0.03, ins=0.08, dele=0.05):
+    q = bytearray()
+    for c in t:
+        u = rng.random()
+        if u < dele:
+            continue
+        q.append(c if u > dele + sub else b"ACGT"[rng.integers(0, 4)])
+        while rng.random() < ins:
+            q.append(b"ACGT"[rng.integers(0, 4)])
+    return bytes(q)
+
+
+def test_align_kat_and_twin(gpu_ctx_factory, monkeypatch):
+    """dagcon_align against its CPU twin (oracle.banded_align), bit for bit: the reference's one
+    known-answer test (test/cpp/SimpleAlignerTest.cpp:8-21), empty and one-base sequences, pairs of
+    very different lengths (band edges), pairs of several thousand bases (band narrower than the
+    matrix, directions staged through LDS in many rounds), and several launch groups."""
+    import json
+    import os
+    k = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kat_graph.json")))["simple_aligner"]
+    ctx = gpu_ctx_factory()
+    (qa, ta), = ctx.align([(k["qstr"].encode(), k["tstr"].encode())])
+    rc = bytes.maketrans(b"ACGT", b"TGCA")
+    assert ta.translate(rc)[::-1].decode() == k["expected_tstr"]
+    assert (qa, ta) == oracle.banded_align(k["qstr"].encode(), k["tstr"].encode())
+    rng = np.random.default_rng(44)
+    pairs = [(b"", b""), (b"A", b""), (b"", b"ACGT"), (b"A", b"A"), (b"A", b"C"), (b"ACGTACGT", b"A"), (b"G", b"ACGTACGG")]
+    for i in range(60):
+        t = bytes(b"ACGT"[j] for j in rng.integers(0, 4, int(rng.integers(1, 300))))
+        q = _mutate(rng, t) if i % 3 else bytes(b"ACGT"[j] for j in rng.integers(0, 4, int(rng.integers(1, 300))))
+        pairs.append((q, t))
+    for n in (1500, 4000, 9000):
+        t = bytes(b"ACGT"[j] for j in rng.integers(0, 4, n))
+        pairs.append((_mutate(rng, t), t))
+        pairs.append((_mutate(rng, t, ins=0.2), t[: n // 2]))       # the band does not reach the corner cleanly
+    exp = [oracle.banded_align(q, t) for q, t in pairs]
+    assert ctx.align(pairs) == exp
+    monkeypatch.setenv("DAGCON_ALIGN_ROWS", "5000")                 # several launch groups
+    assert ctx.align(pairs) == exp
+
+
+def test_cli_pre_input_with_align(tmp_path):
+    """pbdagcon -a file.pre: parsePre (Alignment.cpp:82-112), every record re-aligned
+    (main.cpp:127-128, SimpleAligner.cpp:25-63: start / end arithmetic, '-' strand reverse
+    complement), then the usual path; against the same steps on the CPU (twin aligner + oracle)."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cli = os.path.join(root, "pbdagcon_amd", "bin", "pbdagcon")
+    rng = np.random.default_rng(8)
+    rc = bytes.maketrans(b"ACGT", b"TGCA")
+    lines, exp = [], []
+    for ti in range(4):
+        tlen = int(rng.integers(1500, 2500))
+        target = bytes(b"ACGT"[j] for j in rng.integers(0, 4, tlen))
+        alns = []
+        for r in range(10 if ti != 2 else 3):                       # target 2 stays below -c 6
+            s = int(rng.integers(0, tlen // 4)); e = int(rng.integers(3 * tlen // 4, tlen + 1))
+            strand = b"+-"[r % 2:r % 2 + 1]
+            # m4topre.py:194-206 hands over the target substring in the read's orientation
+            tseq = target[s:e] if strand == b"+" else target[s:e].translate(rc)[::-1]
+            qseq = _mutate(rng, tseq)
+            tstart = s if strand == b"+" else tlen - e
+            lines.append(b" ".join([b"q%d_%d" % (ti, r), b"t%d" % ti, strand, b"%d" % tlen, b"%d" % tstart,
+                                    b"%d" % (tstart + len(tseq)), qseq, tseq]))
+            st, en, qa, ta = oracle.simple_align(tstart, tlen, strand, qseq, tseq)
+            alns.append((st, qa, ta))
+        if len(alns) >= 6:
+            for r0, r1, s_ in oracle.consensus_target(tlen, alns, 500, 50, 6):
+                exp.append(b">t%d/%d_%d\n%s\n" % (ti, r0, r1, s_))
+    path = tmp_path / "in.pre"
+    path.write_bytes(b"\n".join(lines) + b"\n")
+    out = subprocess.run([cli, "-a", "-j", "2", str(path)], capture_output=True, timeout=300)
+    assert out.returncode == 0, out.stderr.decode()
+    assert out.stdout == b"".join(exp) and len(exp) == 3

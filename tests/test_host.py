@@ -150,7 +150,7 @@ def test_cli_parser_matches_reference_parser(tmp_path):
 def test_cli_flags_and_errors(tmp_path):
     cli = _cli()
     assert subprocess.run([cli], capture_output=True).returncode == 2                 # input is required
-    assert subprocess.run([cli, "-a", "x.m5"], capture_output=True).returncode == 2  # -a needs blasr_libcpp
+    assert subprocess.run([cli, "-a", "x.pre"], capture_output=True).returncode == 1  # -a: .pre input (a missing file is an error)
     assert subprocess.run([cli, "--dump-parsed", str(tmp_path / "nope.m5")], capture_output=True).returncode == 1
     bad = tmp_path / "bad.m5"
     bad.write_text("only three fields\n")
