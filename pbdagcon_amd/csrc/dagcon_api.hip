@@ -64,13 +64,14 @@ struct Ctx {
     DevBuf d_node_base, d_n_nodes, d_pool_base, d_pool_size, d_pool_top, d_t_nins;
     DevBuf d_matA, d_matD, d_matC, d_cov, d_gcount, d_gbase, d_bid;
     DevBuf d_nodes, d_best, d_queue, d_score, d_cns_tmp, d_bp_tt;
-    DevBuf d_pool, d_stk, d_cuts, d_cuts_bp, d_bp_stat, d_bp_len, d_nextcut, d_tile_list;
+    DevBuf d_pool, d_stk, d_cuts, d_cuts_bp, d_bp_stat, d_bp_len, d_nextcut, d_tile_list, d_rd, d_pro_state, d_forb, d_sh_cnt, d_seg_done, d_wl_first, d_queue0;
     DevBuf d_al[12];                                // dagcon_align: blobs, offsets, outputs, directions
     DevBuf d_cns, d_cns_off, d_cns_len, d_seg_first, d_n_seg, d_seg_r0, d_seg_r1, d_st;
 
     uint64_t norm_cap = 0, node_cap = 0, pool_cap = 0, cns_cap = 0, seg_cap = 0;
     uint32_t stk_words = 4096, growth_pct = 100, seg_max = 8, bp_max = 16, seg_env = 0;    // (scratch per target and segment: grown x4 and re-run on DG_E_STACK)
-    uint32_t tile_pos = 0, tile_words = 0, tile_ny = 0, tile_list_cap = 0, list_grid = 4096;   // LDS tiles (tile_pos 0: off)
+    uint32_t gcuts = 1;                             // partial-span cuts: prologue + worklist + epilogue (DAGCON_GCUTS=0: off)
+    uint32_t tile_pos = 0, tile_words = 0, tile_ny = 0, tile_list_cap = 0, list_grid = 8192;   // LDS tiles (tile_pos 0: off)
     double ins_per_pos = -1.0;                      // inserted vertices per backbone position, from the last run
     uint64_t expected_workers = 0;                  // merge workers the batch will probably run (prefetch on / off)
 
@@ -150,10 +151,17 @@ int ensure_arenas(Ctx *c) {
     ENSURE(c, c->d_bp_tt, c->node_cap * 4);
     ENSURE(c, c->d_cns_tmp, c->node_cap);
     ENSURE(c, c->d_pool, c->pool_cap * 4);
-    ENSURE(c, c->d_stk, std::max<uint64_t>((uint64_t)c->T * c->bp_max, c->tile_pos ? c->list_grid : 0) * c->stk_words * 4);       // (bp_max >= seg_max)
-    if (c->tile_pos) {
-        ENSURE(c, c->d_nextcut, c->sum_bb * 4);
-        ENSURE(c, c->d_tile_list, (4ull + 3ull * c->tile_list_cap) * 4);
+    ENSURE(c, c->d_stk, std::max<uint64_t>((uint64_t)c->T * c->bp_max, (c->tile_pos || c->gcuts) ? c->list_grid : 0) * c->stk_words * 4);       // (bp_max >= seg_max)
+    if (c->tile_pos) ENSURE(c, c->d_nextcut, c->sum_bb * 4);
+    if (c->tile_pos || c->gcuts) ENSURE(c, c->d_tile_list, (4ull + 3ull * c->tile_list_cap) * 4);
+    if (c->gcuts) {
+        ENSURE(c, c->d_rd, (uint64_t)c->A * 16 + 16);
+        ENSURE(c, c->d_pro_state, (uint64_t)c->T * 16 + 16);
+        ENSURE(c, c->d_forb, (uint64_t)c->T * (2 * DG_FORB_MAX + 1) * 4 + 16);
+        ENSURE(c, c->d_sh_cnt, (uint64_t)c->T * 8 + 16);
+        ENSURE(c, c->d_seg_done, (uint64_t)c->tile_list_cap * 4 + 16);
+        ENSURE(c, c->d_wl_first, (uint64_t)c->T * 4 + 16);
+        ENSURE(c, c->d_queue0, c->node_cap * 4);
     }
     ENSURE(c, c->d_cuts, (uint64_t)c->T * (c->seg_max + 2) * 4);
     ENSURE(c, c->d_cuts_bp, (uint64_t)c->T * (c->bp_max + 2) * 4);
@@ -214,6 +222,11 @@ void fill_params(Ctx *c, DgParams &p) {
     // workers hide each other's latency and it only takes issue slots from them
     { const char *e = getenv("DAGCON_PF_AHEAD"); p.pf_ahead = e ? (uint32_t)atoi(e) : (c->expected_workers >= 4096 ? 0u : 48u); }
     p.seg_max = c->seg_max; p.seg_min = c->opts.min_segment_len ? c->opts.min_segment_len : 768u; p.cuts = (uint32_t *)c->d_cuts.p; p.bp_max = c->bp_max; p.cuts_bp = (uint32_t *)c->d_cuts_bp.p; p.bp_stat = (float *)c->d_bp_stat.p; p.bp_len = (uint32_t *)c->d_bp_len.p;
+    p.gcuts = c->gcuts;
+    p.rd_s = (uint32_t *)c->d_rd.p; p.rd_e = p.rd_s + c->A; p.rd_lead = p.rd_e + c->A; p.rd_trail = p.rd_lead + c->A;
+    p.pro_state = (uint32_t *)c->d_pro_state.p; p.forb = (uint32_t *)c->d_forb.p; p.sh_cnt = (uint32_t *)c->d_sh_cnt.p;
+    p.queue0 = (int32_t *)c->d_queue0.p;
+    p.seg_done = (uint32_t *)c->d_seg_done.p; p.wl_first = (uint32_t *)c->d_wl_first.p;
     p.nextcut = (uint32_t *)c->d_nextcut.p; p.tile_pos = c->tile_pos; p.tile_words = c->tile_words;
     p.tile_list = (uint32_t *)c->d_tile_list.p; p.tile_list_cap = c->tile_list_cap;
     p.cns = (uint8_t *)c->d_cns.p; p.cns_cap = c->cns_cap;
@@ -254,6 +267,7 @@ int launch_all(Ctx *c) {
     hipLaunchKernelGGL(k_carve, dim3(1), dim3(1024), 0, s, p);
     if (c->T > 0) {
         const uint32_t rows4 = (c->max_tlen + 2 + 4 * DG_LPW - 1) / (4 * DG_LPW);   // 4 waves x DG_LPW positions per block
+        if (c->gcuts && c->A > 0) hipLaunchKernelGGL(k_readspan, dim3((c->A + 63) / 64), dim3(64), 0, s, p);   // (before matC becomes prefix sums)
         hipLaunchKernelGGL(k_groups, dim3(c->T, (c->max_tlen + 2 + 31) / 32), dim3(256), 0, s, p);
         hipLaunchKernelGGL(k_gscan, dim3(c->T), dim3(1024), 0, s, p);
         if (c->A > 0)
@@ -267,7 +281,15 @@ int launch_all(Ctx *c) {
     HIPCHK(c, hipEventRecord(c->ev[2], s));
     if (c->T > 0 && !(c->opts.flags & DAGCON_FLAG_STOP_AFTER_BUILD)) {
         hipLaunchKernelGGL(k_cuts, dim3(c->T), dim3(64), 0, s, p);
-        if (c->tile_pos) {
+        if (c->gcuts && !c->tile_pos) {
+            // partial-span cuts: enter and what hangs on it first, then the segments as a worklist, exit last
+            HIPCHK(c, hipMemsetAsync(c->d_tile_list.p, 0, 16, s));
+            HIPCHK(c, hipMemsetAsync(c->d_seg_done.p, 0, (size_t)c->tile_list_cap * 4, s));
+            hipLaunchKernelGGL(k_merge_pro, dim3(c->T), dim3(64), 0, s, p);
+            hipLaunchKernelGGL(k_cuts2, dim3(c->T), dim3(64), 0, s, p);
+            hipLaunchKernelGGL(k_merge_list, dim3(c->list_grid), dim3(64), 0, s, p);
+            hipLaunchKernelGGL(k_merge_fin, dim3(c->T), dim3(64), 0, s, p);
+        } else if (c->tile_pos) {
             HIPCHK(c, hipMemsetAsync(c->d_tile_list.p, 0, 16, s));
             HIPCHK(c, hipFuncSetAttribute((const void *)k_merge_tile, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(c->tile_words * 4)));
             hipLaunchKernelGGL(k_cutmap, dim3(c->T), dim3(1024), 0, s, p);
@@ -353,7 +375,7 @@ void dagcon_destroy(dagcon_ctx *ctx) {
                      &c->d_n_ins, &c->d_n_del, &c->d_norm, &c->d_node_base, &c->d_n_nodes,
                      &c->d_pool_base, &c->d_pool_size, &c->d_pool_top, &c->d_t_nins, &c->d_matA, &c->d_matD,
                      &c->d_matC, &c->d_cov, &c->d_gcount, &c->d_gbase, &c->d_bid, &c->d_nodes,
-                     &c->d_best, &c->d_queue, &c->d_score, &c->d_cns_tmp, &c->d_bp_tt, &c->d_pool, &c->d_stk, &c->d_cuts, &c->d_cuts_bp, &c->d_bp_stat, &c->d_bp_len, &c->d_nextcut, &c->d_tile_list, &c->d_cns,
+                     &c->d_best, &c->d_queue, &c->d_score, &c->d_cns_tmp, &c->d_bp_tt, &c->d_pool, &c->d_stk, &c->d_cuts, &c->d_cuts_bp, &c->d_bp_stat, &c->d_bp_len, &c->d_nextcut, &c->d_tile_list, &c->d_rd, &c->d_pro_state, &c->d_forb, &c->d_sh_cnt, &c->d_seg_done, &c->d_wl_first, &c->d_queue0, &c->d_cns,
                      &c->d_cns_off, &c->d_cns_len, &c->d_seg_first, &c->d_n_seg, &c->d_seg_r0, &c->d_seg_r1,
                      &c->d_st};
     for (DevBuf *b : all) free_buf(*b);
@@ -447,6 +469,8 @@ int dagcon_upload(dagcon_ctx *ctx, const dagcon_batch *b) {
             bb_bytes = std::max<uint64_t>(bb_bytes, b->backbone_off[t] + b->tlen[t]);
         }
     }
+    if (const char *e = getenv("DAGCON_GCUTS")) c->gcuts = atoi(e) ? 1u : 0u;
+    if (c->gcuts) c->tile_list_cap = std::max<uint32_t>(c->tile_list_cap, (uint32_t)std::min<uint64_t>((uint64_t)T * c->seg_max + 64, 0x0FFFFFFFull));
     // LDS tiles for mergeNodes: positions per tile from the LDS budget and the expected size of a
     // position's share of the graph (exact after the first run of a shape)
     {

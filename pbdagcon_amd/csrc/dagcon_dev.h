@@ -81,6 +81,8 @@ struct __attribute__((aligned(16))) DgNode {
 #define DG_MAX_NODES    0x1FFFFFDu
 #define DG_EMIT_SEG     512u   // backbone positions per k_emit wave: default of DgParams::emit_shift (1 << 9)
 #define DG_CK_NONE      0xFFFFFFFFu
+#define DG_FORB_MAX     64u
+#define DG_TOMB         0xFFFFFFFFu   // erased entry of a shared list (enter's out-list, exit's in-list)
 
 struct DgParams {
     // ---- inputs (resident in HBM after dagcon_upload) ----
@@ -162,6 +164,17 @@ struct DgParams {
     uint32_t *cuts_bp;             //   its waves are light), [T][bp_max + 2] like cuts
     float *bp_stat;                // [T][seg_max][2]: largest |score| of the segment, score of its first vertex
     uint32_t *bp_len;              // [T][seg_max]: vertices of the best path inside the segment (enter / exit excluded)
+    // ---- cuts for partial-span pileups (k_readspan, k_merge_pro, k_cuts2, k_merge_list, k_merge_fin) ----
+    uint32_t gcuts;                // 1: mergeNodes runs as prologue + worklist of segments + epilogue
+    uint32_t *rd_s, *rd_e;         // [A] first / last backbone position a read consumes (0 / 0: the read is empty)
+    uint32_t *rd_lead, *rd_trail;  // [A] insertion run in front of the first / behind the last position
+    int32_t *queue0;               // FIFO of the prologue and of the segment that resumes it (it also holds the vertices
+                                   // the prologue visits beyond that segment: a stretch of `queue` would be too short)
+    uint32_t *pro_state;           // [T][4]: queue head, queue tail of the prologue, vertices it visited, 1 = no cuts allowed
+    uint32_t *forb;                // [T][2 * DG_FORB_MAX + 1]: count, then (lo, hi) vertex id pairs no cut may lie strictly inside
+    uint32_t *sh_cnt;              // [T][2]: physical entries of enter's out-list / exit's in-list (shared lists)
+    uint32_t *seg_done;            // [tile_list_cap]: 1 = the worklist entry has finished
+    uint32_t *wl_first;            // [T]: worklist index of the target's first segment
     // ---- LDS tiles (k_cutmap, k_merge_tile, k_merge_list) ----
     uint32_t *nextcut;             // [bbv_base + p]: smallest cut position >= p (k_cutmap)
     uint32_t tile_pos;             // backbone positions per tile (0: tiles are not used)

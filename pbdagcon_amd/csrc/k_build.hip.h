@@ -646,6 +646,47 @@ __global__ __launch_bounds__(1024) void k_carve(DgParams p) {
 }
 
 // ---------------------------------------------------------------------------
+// k_readspan: lane per alignment.  What the cuts of mergeNodes need to know about partial-span reads:
+//   rd_lead  insertion columns in front of the read's first MATCH column: those vertices hang on enter
+//            alone (addAln's `prev` is still enter: deletion columns in between do not move it);
+//   rd_e     backbone position of the read's last match column, rd_trail the insertion columns behind it:
+//            a chain that leads to exit only;  rd_s: position of the first match column.
+// A read without a match column is one chain from enter to exit (all of it `lead`).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_readspan(DgParams p) {
+    const uint32_t a = blockIdx.x * 64 + threadIdx.x;
+    if (a >= p.A) return;
+    if (dg_failed(p)) return;
+    const uint32_t t = p.aln_tgt[a];
+    uint32_t s = 0, e = 0, lead = 0, trail = 0;
+    if (!dg_tskip(p, t)) {
+        const uint32_t lo = p.n_lo[a], hi = p.n_hi[a];
+        if (hi > lo && hi != DG_REDO) {
+            const uint16_t *col = p.norm + p.norm_off[a];
+            const uint32_t ins = p.n_ins[a];
+            uint32_t i = lo, dels = 0;
+            for (; i < hi; i++) {
+                const uint8_t qb = DG_Q(col[i]), tb = DG_T(col[i]);
+                if (qb == tb) break;
+                if (tb == DG_GAP) lead++; else if (qb == DG_GAP) dels++;
+            }
+            s = p.n_start[a] + dels;
+            if (i < hi) {
+                uint32_t k = hi, tdels = 0;
+                while (k > i + 1) {
+                    const uint8_t qb = DG_Q(col[k - 1]), tb = DG_T(col[k - 1]);
+                    if (qb == tb) break;
+                    if (tb == DG_GAP) trail++; else if (qb == DG_GAP) tdels++;
+                    k--;
+                }
+                e = p.n_start[a] + (hi - lo - ins) - 1u - tdels;
+            } else { e = 0; s = 0; }
+        }
+    }
+    p.rd_s[a] = s; p.rd_e[a] = e; p.rd_lead[a] = lead; p.rd_trail[a] = trail;
+}
+
+// ---------------------------------------------------------------------------
 // k_groups: one wave per 8 backbone positions.  matC column -> exclusive prefix over
 // reads (in place); gcount[p] = inserted vertices whose _bbMap is p.
 // ---------------------------------------------------------------------------

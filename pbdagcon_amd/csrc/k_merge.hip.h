@@ -48,6 +48,23 @@ struct DgGraph {
     uint32_t *tfail;               // this target's word of DgParams::tfail
     uint32_t t;
     bool err;
+    // Partial-span pileups (k_cuts2): reads that start or end inside the target put enter -> x and
+    // x -> exit edges across the cut vertices, so enter's out-list and exit's in-list are touched by
+    // every segment's worker.  Entries of such a list belong to the segment of the vertex they name,
+    // and a worker only ever looks for, changes or erases entries of its own segment; what the
+    // reference's order fixes is the ORDER OF APPENDS, and all visits of segment i precede all visits
+    // of segment i + 1 in the reference's FIFO (the cut argument above k_cuts).  Hence the protocol
+    // (sh != 0): an erase leaves a tombstone (nobody's entries move), an append waits until every
+    // earlier segment of the target has finished and then takes the next slot from an atomic cursor
+    // (the slack behind the list is tombstones, put there by the prologue), and k_merge_fin squeezes the
+    // tombstones out before it visits the exit vertex.  Neither vertex can be a member of a merge group
+    // ('^' and '$' are nobody else's base).
+    int sh;                        // 1: the protocol is on (workers of k_merge_list)
+    int X;                         // the exit vertex
+    uint32_t *sh_cnt;              // [0] physical entries of out[enter], [1] of in[exit]
+    uint32_t *done;                // DgParams::seg_done
+    uint32_t wait_lo, wait_hi;     // worklist entries of the earlier segments of this target
+    bool waited;
 };
 
 __device__ __forceinline__ void dgg_fail(DgGraph &g, uint32_t bit) {
@@ -76,22 +93,38 @@ __device__ __forceinline__ void dgw_fail(DgGraph &g, uint32_t bit, int lane) {
     } while (0)
 
 // ---- ordered slot lists (single lane) --------------------------------------
+#define DGG_SH_OUT(g, v) ((g).sh && (v) == 0)
+#define DGG_SH_IN(g, v) ((g).sh && (v) == (g).X)
+// appends to a shared list come in segment order: wait for the earlier segments of the target
+__device__ inline void dgg_wait_pred(DgGraph &g) {
+    if (g.waited) return;
+    for (uint32_t i = g.wait_lo; i < g.wait_hi && !g.err; i++) {
+        unsigned spins = 0;
+        while (atomicAdd(&g.done[i], 0u) == 0u) {
+            __builtin_amdgcn_s_sleep(16);
+            if (++spins > (1u << 23)) { dgg_fail(g, DG_E_INTERNAL); break; }      // (every spin is bounded)
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    g.waited = true;
+}
 __device__ inline int dgg_out_find(DgGraph &g, int v, int dst) {
     const uint32_t off = g.nd[v].out_off;
-    const int n = g.nd[v].out_len;
+    const int n = DGG_SH_OUT(g, v) ? (int)atomicAdd(&g.sh_cnt[0], 0u) : (int)g.nd[v].out_len;
     for (int i = 0; i < n; i++)
         if ((int)g.pool[off + 2 * i] == dst) return i;
     return -1;
 }
 __device__ inline int dgg_in_find(DgGraph &g, int v, int src) {
     const uint32_t off = g.nd[v].in_off;
-    const int n = g.nd[v].in_len;
+    const int n = DGG_SH_IN(g, v) ? (int)atomicAdd(&g.sh_cnt[1], 0u) : (int)g.nd[v].in_len;
     for (int i = 0; i < n; i++)
         if ((int)g.pool[off + i] == src) return i;
     return -1;
 }
 __device__ inline void dgg_out_erase(DgGraph &g, int v, int idx) {
     const uint32_t off = g.nd[v].out_off;
+    if (DGG_SH_OUT(g, v)) { g.pool[off + 2 * idx] = DG_TOMB; g.pool[off + 2 * idx + 1] = 0u; return; }
     const int n = g.nd[v].out_len;
     for (int i = idx; i + 1 < n; i++) {
         g.pool[off + 2 * i] = g.pool[off + 2 * i + 2];
@@ -101,6 +134,7 @@ __device__ inline void dgg_out_erase(DgGraph &g, int v, int idx) {
 }
 __device__ inline void dgg_in_erase(DgGraph &g, int v, int idx) {
     const uint32_t off = g.nd[v].in_off;
+    if (DGG_SH_IN(g, v)) { g.pool[off + idx] = DG_TOMB; return; }
     const int n = g.nd[v].in_len;
     for (int i = idx; i + 1 < n; i++) g.pool[off + i] = g.pool[off + i + 1];
     g.nd[v].in_len = (uint16_t)(n - 1);
@@ -112,6 +146,14 @@ __device__ inline uint32_t dgg_alloc(DgGraph &g, uint32_t words) {
 }
 __device__ inline void dgg_out_append(DgGraph &g, int v, int dst, int count) {
     uint32_t off = g.nd[v].out_off;
+    if (DGG_SH_OUT(g, v)) {
+        dgg_wait_pred(g);
+        if (g.err) return;
+        const uint32_t i = atomicAdd(&g.sh_cnt[0], 1u);
+        if (i >= g.nd[v].out_cap) { dgg_fail(g, DG_E_POOL_TGT); return; }     // (re-run with more slack)
+        g.pool[off + 2 * i] = (uint32_t)dst; g.pool[off + 2 * i + 1] = (uint32_t)count;
+        return;
+    }
     const int n = g.nd[v].out_len;
     if (n >= g.nd[v].out_cap) {
         uint32_t ncap = 2u * (uint32_t)(n + 1);
@@ -129,6 +171,14 @@ __device__ inline void dgg_out_append(DgGraph &g, int v, int dst, int count) {
 }
 __device__ inline void dgg_in_append(DgGraph &g, int v, int src) {
     uint32_t off = g.nd[v].in_off;
+    if (DGG_SH_IN(g, v)) {
+        dgg_wait_pred(g);
+        if (g.err) return;
+        const uint32_t i = atomicAdd(&g.sh_cnt[1], 1u);
+        if (i >= g.nd[v].in_cap) { dgg_fail(g, DG_E_POOL_TGT); return; }
+        g.pool[off + i] = (uint32_t)src;
+        return;
+    }
     const int n = g.nd[v].in_len;
     if (n >= g.nd[v].in_cap) {
         uint32_t ncap = 2u * (uint32_t)(n + 1);
@@ -171,7 +221,7 @@ __device__ inline int dgg_push_in_frame(DgGraph &g, int sp, int fp, int n) {
     int nc = 0;
     for (int i = 0; i < len; i++) {
         const int s = (int)g.pool[off + i];
-        if (g.nd[s].out_len == 1) nc++;
+        if (g.nd[s].out_len == 1 && !DGG_SH_OUT(g, s)) nc++;
     }
     if (nc < 2) return -1;
     if ((uint32_t)(sp + 3 + 2 * nc) > g.stk_words) { dgg_fail(g, DG_E_STACK); return -1; }
@@ -179,7 +229,7 @@ __device__ inline int dgg_push_in_frame(DgGraph &g, int sp, int fp, int n) {
     int k = 0;
     for (int i = 0; i < len; i++) {
         const int s = (int)g.pool[off + i];
-        if (g.nd[s].out_len == 1) { g.stk[sp + 3 + k] = s; g.stk[sp + 3 + nc + k] = g.nd[s].base; k++; }
+        if (g.nd[s].out_len == 1 && !DGG_SH_OUT(g, s)) { g.stk[sp + 3 + k] = s; g.stk[sp + 3 + nc + k] = g.nd[s].base; k++; }
     }
     return sp + 3 + 2 * nc;
 }
@@ -261,7 +311,7 @@ __device__ inline void dgg_merge_out(DgGraph &g, int n) {
     int nc = 0;
     for (int i = 0; i < len; i++) {
         const int d = (int)g.pool[off + 2 * i];
-        if (g.nd[d].in_len == 1) nc++;
+        if (g.nd[d].in_len == 1 && !DGG_SH_IN(g, d)) nc++;
     }
     if (nc < 2) return;
     if ((uint32_t)(2 * nc) > g.stk_words) { dgg_fail(g, DG_E_STACK); return; }
@@ -270,7 +320,7 @@ __device__ inline void dgg_merge_out(DgGraph &g, int n) {
         int k = 0;
         for (int i = 0; i < len; i++) {
             const int d = (int)g.pool[off + 2 * i];
-            if (g.nd[d].in_len == 1) { ids[k] = d; bases[k] = g.nd[d].base; k++; }
+            if (g.nd[d].in_len == 1 && !DGG_SH_IN(g, d)) { ids[k] = d; bases[k] = g.nd[d].base; k++; }
         }
     }
     int last = -1;
@@ -316,7 +366,7 @@ __device__ inline void dgg_merge_out(DgGraph &g, int n) {
                 dgg_in_erase(g, n2, kin);
                 if (ka >= 0) {
                     g.pool[g.nd[an].out_off + 2 * ka + 1] += (uint32_t)c;
-                    g.nd[n2].pending -= 1;   // the victim's unvisited in-edge disappears
+                    if (!DGG_SH_IN(g, n2)) g.nd[n2].pending -= 1;   // the victim's unvisited in-edge disappears
                 } else {
                     dgg_out_append(g, an, n2, c);
                     dgg_in_append(g, n2, an);
@@ -510,6 +560,7 @@ __device__ inline bool dgw_merge_out_group(DgGraph &g, int u, const DgNode &nu, 
     uint4 hn2 = make_uint4(0, 0, 0, 0);
     if (vic_entry) hn2 = dg_lo16(&DG_NV(g, n2));
     if (__ballot(vic_entry && DG_H_INLEN(hn2) > 64)) return false;
+    if (g.sh && __ballot(vic_entry && n2 == g.X)) return false;      // in[exit] is shared: literal path
 
     // ---- nothing has been modified up to here ----
     // :236-243 count(u->an) += counts of u->victims, weight[an] += weights
@@ -615,6 +666,7 @@ __device__ inline bool dgw_merge_in_group(DgGraph &g, int n, const DgNode &nn, u
     uint4 hn1 = make_uint4(0, 0, 0, 0);
     if (fl) hn1 = dg_lo16(&DG_NV(g, n1));
     if (__ballot(fl && DG_H_OUTLEN(hn1) > 64)) return false;
+    if (g.sh && __ballot(fl && n1 == 0)) return false;                // out[enter] is shared: literal path
 
     // ---- nothing has been modified up to here ----
     // :183-190 survivor's out edge count and weight
@@ -749,7 +801,7 @@ __global__ __launch_bounds__(64) void k_cuts(DgParams p) {
             }
             if (found) { if (lane == 0) out[1 + nseg] = found; nseg++; }
         }
-        if (lane == 0) { out[0] = nseg; if (which == 0 && !p.tile_pos) atomicAdd(&p.st->n_mseg, nseg); }
+        if (lane == 0) { out[0] = nseg; if (which == 0 && !p.tile_pos && !p.gcuts) atomicAdd(&p.st->n_mseg, nseg); }
     }
 }
 
@@ -762,9 +814,19 @@ __global__ __launch_bounds__(64) void k_cuts(DgParams p) {
 #define DG_PROG_SET(x) __hip_atomic_store(&s_prog, (x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
 // One segment [c_start, c_end] of target t, swept by the calling wave (PF: by the first wave of the
 // block, the second prefetches).  c_end = 0x7fffffff: the segment runs to the exit vertex.
+// mode DG_MM_WORKER: a segment between two cuts (with p.gcuts: enter / exit shared, exit not visited, the
+//                      segment that starts at enter resumes where the prologue stopped);
+//      DG_MM_PROLOGUE: from enter, every visit up to FIFO level `lvl_stop` (the enter visit and the
+//                      chains that hang on enter alone), wherever the vertices lie; the queue state is left
+//                      in p.pro_state for the first worker;
+//      DG_MM_FINISH:   the exit vertex alone (mergeInNodes(exit) and its recursion), after every worker.
+#define DG_MM_WORKER 0
+#define DG_MM_PROLOGUE 1
+#define DG_MM_FINISH 2
 template <bool PF>
 __device__ __forceinline__ void dg_merge_segment(const DgParams &p, const uint32_t t, const int c_start, const int c_end,
-                                                 int32_t *stk_base) {
+                                                 int32_t *stk_base, const int mode = DG_MM_WORKER, const uint32_t me = 0,
+                                                 const uint32_t wlo = 0, const int lvl_stop = 0) {
     const int lane = threadIdx.x & 63;
     const uint64_t nb = p.node_base[t];
     const uint32_t NT = p.n_nodes[t];
@@ -780,16 +842,28 @@ __device__ __forceinline__ void dg_merge_segment(const DgParams &p, const uint32
         return;
     }
     DgGraph g;
-    g.nd = p.nodes + nb; g.queue = p.queue + nb + c_start;          // the segment's own stretch of the queue
+    const bool own_q = p.gcuts && c_start == 0 && mode != DG_MM_FINISH;     // (see DgParams::queue0)
+    g.nd = p.nodes + nb; g.queue = own_q ? p.queue0 + nb : p.queue + nb + c_start;          // the segment's own stretch of the queue
     g.pool = p.pool + p.pool_base[t]; g.pool_size = p.pool_size[t]; g.pool_top = p.pool_top + t;
     g.stk = stk_base; g.stk_words = p.stk_words;
     g.st = p.st; g.tfail = p.tfail + t; g.t = t; g.err = false;
-    const uint32_t N = (uint32_t)(c_hi - c_start + 1);               // vertices this worker can dequeue
+    const bool sh = p.gcuts && mode == DG_MM_WORKER;
+    g.sh = sh ? 1 : 0; g.X = (int)NT - 1; g.sh_cnt = p.sh_cnt + 2u * t; g.done = p.seg_done;
+    g.wait_lo = wlo; g.wait_hi = me; g.waited = false;
+    const int X = sh ? (int)NT - 1 : -1;                               // exit, where it must be left alone
+    const uint32_t N = own_q ? NT : (uint32_t)(c_hi - c_start + 1);     // vertices this worker can dequeue
     __shared__ int s_stk[2 * DG_IN_STACK];
     __shared__ int s_ring[DG_QRING];                     // the youngest DG_QRING queue entries
     uint32_t qh = 0, qt = 1;
-    if (lane == 0) { g.queue[0] = c_start; s_ring[0] = c_start; }    // enter vertex / cut vertex
+    if (sh && c_start == 0) {
+        // the prologue has visited enter (and what hangs on it alone): go on from its queue
+        qh = p.pro_state[4u * t]; qt = p.pro_state[4u * t + 1u];
+        for (uint32_t i = qh + (uint32_t)lane; i < qt; i += 64) s_ring[i & (DG_QRING - 1)] = g.queue[i];
+    } else if (lane == 0) { g.queue[0] = c_start; s_ring[0] = c_start; }    // enter vertex / cut vertex
     DG_WAVE_FENCE();
+    // FIFO levels (prologue): entries [.., lvl_end) belong to level lvl
+    int lvl = 0;
+    uint32_t lvl_end = 1;
     int failed = 0;
     int prog = c_start;
     int u_next = 0;
@@ -800,6 +874,11 @@ __device__ __forceinline__ void dg_merge_segment(const DgParams &p, const uint32
     unsigned long long c_fast = 0, c_slow = 0, n_fast = 0, n_slow = 0, n_scalar = 0, t_prev = clock64(), c_a = 0, c_b = 0, c_c = 0, c_grp = 0, ng_in = 0, ng_out = 0, c_odd = 0, n_odd = 0, q_a = 0, q_b = 0, q_c = 0, q_d = 0;
 #endif
     while (qh < qt && !failed) {
+        if (mode == DG_MM_PROLOGUE) {
+            if (qh == lvl_end) { lvl++; lvl_end = qt; }
+            if (lvl > lvl_stop) break;
+            have_next = false;                            // (the look-ahead below assumes nothing about levels)
+        }
         // an entry still in the LDS ring has not been overwritten: pushes so far are < qt <= qh + DG_QRING
         int u;
         const bool pre = have_next;
@@ -815,13 +894,15 @@ __device__ __forceinline__ void dg_merge_segment(const DgParams &p, const uint32
         const unsigned long long ts0 = clock64();
 #endif
         if (PF && u > prog + 15) { prog = u; if (lane == 0) DG_PROG_SET(u); }
-        if (u < c_start || u > c_hi) {                    // cannot happen (see k_cuts): refuse rather than race
+        if (mode != DG_MM_PROLOGUE && (u < c_start || u > c_hi)) {    // cannot happen (see k_cuts): refuse rather than race
             dgw_fail(g, DG_E_INTERNAL, lane);
             break;
         }
-        const bool skip_in = c_start != 0 && u == c_start; // the previous segment's worker merges in[u]
+        const bool skip_in = mode == DG_MM_WORKER && c_start != 0 && u == c_start; // the previous segment's worker merges in[u]
         const bool in_only = u == c_end;                  // ... which is this, for the next segment
         if (in_only && qh != qt) { dgw_fail(g, DG_E_INTERNAL, lane); break; }
+        int adj = sh ? -1 : 0;                            // 1: u is a neighbour of the shared enter / exit vertex (-1: not looked yet)
+        if (mode == DG_MM_PROLOGUE && u == (int)NT - 1 && lane == 0) p.pro_state[4u * t + 3u] |= 1u;   // exit visited already
 
         // ---------------- the common case in one look: no merge group on either side --------
         {
@@ -850,7 +931,12 @@ __device__ __forceinline__ void dg_merge_segment(const DgParams &p, const uint32
 #endif
                 uint4 h = make_uint4(0, 0, 0, 0);
                 if (valid) h = dg_lo16(&DG_NV(g, nbr));
-                // in lanes: out_len == 1 (low half of h.x), out lanes: in_len == 1 (high half)
+                // in lanes: out_len == 1 (low half of h.x), out lanes: in_len == 1 (high half); with shared
+                // enter / exit neither is a candidate ('^' / '$' are nobody else's base) and a visit next to
+                // them goes the literal way, where their lists are handled by the protocol
+                const bool shn = sh && valid && (is_in ? nbr == 0 : nbr == X);
+                adj = __ballot(shn) ? 1 : 0;
+                if (adj) goto generic;
                 const unsigned long long cand = __ballot(((h.x >> (is_in ? 0u : 16u)) & 0xffffu) == 1u);
 #ifdef DG_STAMPS
                 const unsigned long long tq3 = clock64();
@@ -920,13 +1006,23 @@ __device__ __forceinline__ void dg_merge_segment(const DgParams &p, const uint32
             }
         }
 
+    generic:
 #ifdef DG_STAMPS
         ts_pre = clock64();
 #endif
         // ---------------- mergeInNodes(u), recursion on an explicit stack ----------------
         int sp = skip_in ? 0 : 1;
         int fr_n = u, fr_last = -1;                       // top frame lives in registers
-        while (sp > 0) {
+        if (adj < 0) {
+            // long lists: look for the shared vertices among u's neighbours
+            const DgNode nq = DG_NV(g, u);
+            bool f = false;
+            if (!skip_in) for (int i = lane; i < nq.in_len; i += 64) f |= DG_PW(g, nq.in_off + i) == 0u;
+            if (!in_only) for (int i = lane; i < nq.out_len; i += 64) f |= (int)DG_PW(g, nq.out_off + 2 * i) == X;
+            adj = __ballot(f) ? 1 : 0;
+        }
+        if (adj) scalar = true;                           // next to enter / exit: the literal path handles their lists
+        while (sp > 0 && !scalar) {
             const DgNode nn = DG_NV(g, fr_n);
             if (nn.in_len > 32) { scalar = true; break; }
             const bool valid = lane < nn.in_len;
@@ -934,7 +1030,7 @@ __device__ __forceinline__ void dg_merge_segment(const DgParams &p, const uint32
             if (valid) s = (int)DG_PW(g, nn.in_off + lane);
             uint4 h = make_uint4(0, 0, 0, 0);
             if (valid) h = dg_lo16(&DG_NV(g, s));
-            const unsigned long long cand = __ballot(valid && DG_H_OUTLEN(h) == 1);
+            const unsigned long long cand = __ballot(valid && DG_H_OUTLEN(h) == 1 && !(sh && s == 0));
             unsigned long long M = 0;
             int b = 256;
             if (__popcll(cand) >= 2) b = dg_pick_group(cand, DG_H_BASE(h), fr_last, lane, &M);
@@ -959,7 +1055,7 @@ __device__ __forceinline__ void dg_merge_segment(const DgParams &p, const uint32
             sp++;                                         // :213 recurse on the survivor
             fr_n = an; fr_last = -1;
         }
-        if (scalar && !g.err) {
+        if (scalar && !g.err && sp > 0) {
             // finish every open frame, deepest first, on the reference-literal path;
             // groups already merged are gone, so re-evaluating a frame from scratch is exact
             DG_LANE0(g, {
@@ -988,7 +1084,7 @@ __device__ __forceinline__ void dg_merge_segment(const DgParams &p, const uint32
             uint4 h = make_uint4(0, 0, 0, 0);
             if (valid) h = dg_lo16(&DG_NV(g, d));
             if (!scalar) {
-                const unsigned long long cand = __ballot(valid && DG_H_INLEN(h) == 1);
+                const unsigned long long cand = __ballot(valid && DG_H_INLEN(h) == 1 && d != X);
                 unsigned long long M = 0;
                 int b = 256;
                 if (__popcll(cand) >= 2) b = dg_pick_group(cand, DG_H_BASE(h), last_out, lane, &M);
@@ -1013,9 +1109,10 @@ __device__ __forceinline__ void dg_merge_segment(const DgParams &p, const uint32
             // AlnGraphBoost.cpp:143-158: mark out-edges visited, enqueue targets whose
             // in-edges are now all visited, in out-list order
             const int pend = DG_H_PEND(h) - 1;
-            if (valid) DG_NV(g, d).pending = pend;
-            const unsigned long long rm = __ballot(valid && pend == 0);
-            if (valid && pend == 0) {
+            const bool bk = valid && d != X;              // (the exit vertex is k_merge_fin's)
+            if (bk) DG_NV(g, d).pending = pend;
+            const unsigned long long rm = __ballot(bk && pend == 0);
+            if (bk && pend == 0) {
                 const uint32_t pos = qt + (uint32_t)__popcll(rm & DG_LT(lane));
                 if (pos < N) { g.queue[pos] = d; s_ring[pos & (DG_QRING - 1)] = d; }
             }
@@ -1032,6 +1129,7 @@ __device__ __forceinline__ void dg_merge_segment(const DgParams &p, const uint32
                 const int len = gs.nd[u].out_len;
                 for (int i = 0; i < len && !gs.err; i++) {
                     const int v = (int)gs.pool[off + 2 * i];
+                    if (v == X) continue;
                     const int pend = gs.nd[v].pending - 1;
                     gs.nd[v].pending = pend;
                     if (pend == 0) {
@@ -1049,6 +1147,14 @@ __device__ __forceinline__ void dg_merge_segment(const DgParams &p, const uint32
 #endif
     }
     if (PF && lane == 0) DG_PROG_SET(DG_PROG_DONE);
+    if (mode == DG_MM_PROLOGUE && lane == 0) {
+        p.pro_state[4u * t] = qh; p.pro_state[4u * t + 1u] = qt; p.pro_state[4u * t + 2u] = qh;
+    }
+    if (sh) {
+        // this segment's appends to the shared lists are over: the next segment may append
+        __threadfence();
+        if (lane == 0) atomicExch(&p.seg_done[me], 1u);
+    }
 #ifdef DG_STAMPS
     if (t == 0 && c_start == 0 && lane == 0) { p.st->dbg[0] = n_fast; p.st->dbg[1] = n_slow; p.st->dbg[2] = c_fast; p.st->dbg[3] = c_slow; p.st->dbg[4] = n_scalar; p.st->dbg[5] = c_a; p.st->dbg[6] = c_b; p.st->dbg[7] = c_c; p.st->dbg[8] = c_grp; p.st->dbg[9] = ng_in; p.st->dbg[10] = ng_out; p.st->dbg[11] = c_odd; p.st->dbg[12] = q_a; p.st->dbg[13] = q_b; p.st->dbg[14] = q_c; p.st->dbg[15] = q_d; }
 #endif
@@ -1067,20 +1173,246 @@ __global__ __launch_bounds__(PF ? 128 : 64) __attribute__((amdgpu_waves_per_eu(8
     dg_merge_segment<PF>(p, t, c_start, c_end, p.stk + (uint64_t)blockIdx.x * p.stk_words);
 }
 
-// the tiles k_merge_tile handed over (p.tile_list: [0] = entries, then (target, first vertex, last
-// vertex or DG_T_NONE) triples): one wave per entry, grid-stride
+// A worklist of segments (p.tile_list: [0] = entries, [2] = ticket cursor, then (target, first vertex,
+// last vertex or DG_NOSEG_END) triples, a target's segments in a row and in order): one wave per
+// entry.  Entries are taken by ticket, so a worker that waits for the earlier segments of its target
+// (dgg_wait_pred) waits for waves that are running or done, whatever the size of the grid.
+#define DG_NOSEG_END 0xFFFFFFFFu
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_merge_list(DgParams p) {
     if (dg_failed(p)) return;
     const uint32_t n = p.tile_list[0] < p.tile_list_cap ? p.tile_list[0] : p.tile_list_cap;
-    for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
+    for (;;) {
+        uint32_t i = 0;
+        if (threadIdx.x == 0) i = atomicAdd(&p.tile_list[2], 1u);
+        i = (uint32_t)__builtin_amdgcn_readfirstlane((int)i);
+        if (i >= n) break;
         const uint32_t t = p.tile_list[4 + 3 * i];
-        if (dg_tskip(p, t)) continue;
         const int c_start = (int)p.tile_list[5 + 3 * i];
         const uint32_t ce = p.tile_list[6 + 3 * i];
-        dg_merge_segment<false>(p, t, c_start, ce == 0xFFFFFFFFu ? 0x7fffffff : (int)ce, p.stk + (uint64_t)blockIdx.x * p.stk_words);
+        if (dg_tskip(p, t)) {
+            if (p.gcuts && threadIdx.x == 0) atomicExch(&p.seg_done[i], 1u);
+            continue;
+        }
+        dg_merge_segment<false>(p, t, c_start, ce == DG_NOSEG_END ? 0x7fffffff : (int)ce, p.stk + (uint64_t)blockIdx.x * p.stk_words,
+                                DG_MM_WORKER, i, p.gcuts ? p.wl_first[t] : 0u);
         if (threadIdx.x == 0) atomicAdd(&p.st->n_mseg, 1u);
         DG_WAVE_FENCE();
     }
     if (blockIdx.x == 0 && threadIdx.x == 0 && p.tile_list[0] > p.tile_list_cap) dg_fail(p, DG_E_LIST_OVF);
+}
+
+// ---- mergeNodes for pileups of partial-span reads: prologue, cuts, epilogue ------------------------
+// A read that starts or ends inside the target puts an enter -> x or x -> exit edge across every
+// backbone vertex it does not reach, so "every read passes through v" (k_cuts) leaves such pileups in
+// one piece.  What is needed of a cut vertex v is weaker: when the reference dequeues v its FIFO holds
+// nothing else, everything in front of v is done and nothing behind it has been touched.  That holds for
+// a backbone vertex v at position p when
+//   (1) every read that COVERS p passes through v (weight - 1 == coverage): no edge of a read jumps over v;
+//   (2) the vertices that hang on enter alone -- the insertion chains reads begin with; mergeOutNodes(enter)
+//       unites the ones with equal bases, wherever on the backbone they lead -- have all been visited
+//       before anything behind v: the FIFO works level by level (level = longest path from enter), such a
+//       chain ends at level `lead` at the latest and v's level is at least p, so k_merge_pro visits levels
+//       0 .. maxlead + 1 first (that IS the reference's order) and cuts lie at p > 2 (maxlead + 2);
+//   (3) no vertex k_merge_pro has visited has out-edges on both sides of v (else two workers would rewrite
+//       one out-list): k_merge_pro records those id ranges, no cut lies inside one;
+//   (4) the dead ends in front of v (the insertion run a read ends with leads to exit only) are done before
+//       v: a read that ends at e < p with a trailing run of r vertices needs p - e > r + 1;
+// and the two vertices every segment touches, enter (out-list) and exit (in-list), follow the protocol
+// described at DgGraph::sh; exit itself is visited last of all, by k_merge_fin.  Every worker still
+// checks that it dequeues no vertex of another segment and that its FIFO is empty when it reaches its
+// end (DG_E_INTERNAL for the target otherwise).
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_merge_pro(DgParams p) {
+    const uint32_t t = blockIdx.x;
+    if (dg_failed(p) || dg_tskip(p, t)) return;
+    const int lane = threadIdx.x;
+    const uint64_t ab = p.aln_begin[t];
+    const uint32_t K = (uint32_t)(p.aln_begin[t + 1] - ab);
+    uint32_t maxlead = 0;
+    for (uint32_t r = lane; r < K; r += 64) { const uint32_t l = p.rd_lead[ab + r]; maxlead = l > maxlead ? l : maxlead; }
+    for (int o = 32; o; o >>= 1) { const uint32_t x = __shfl_xor(maxlead, o); maxlead = x > maxlead ? x : maxlead; }
+    if (lane == 0) { p.pro_state[4u * t + 3u] = 0u; p.forb[(uint64_t)t * (2u * DG_FORB_MAX + 1u)] = 0u; }
+    DG_WAVE_FENCE();
+    dg_merge_segment<false>(p, t, 0, 0x7fffffff, p.stk + (uint64_t)blockIdx.x * p.stk_words, DG_MM_PROLOGUE, 0, 0, (int)maxlead + 1);
+    DG_WAVE_FENCE();
+    if (dg_tskip(p, t)) return;
+    const uint64_t nb = p.node_base[t];
+    DgNode *nd = p.nodes + nb;
+    uint32_t *pool = p.pool + p.pool_base[t];
+    const int32_t *queue = p.queue0 + nb;
+    const uint32_t NT = p.n_nodes[t];
+    const uint32_t nvis = p.pro_state[4u * t + 2u];
+    // (3): out-lists of the visited vertices (enter aside) that reach over more than their own neighbourhood
+    uint32_t *forb = p.forb + (uint64_t)t * (2u * DG_FORB_MAX + 1u);
+    for (uint32_t i0 = 1; i0 < nvis; i0 += 64) {
+        const uint32_t i = i0 + (uint32_t)lane;
+        uint32_t lo = 0xFFFFFFFFu, hi = 0;
+        if (i < nvis) {
+            const int y = queue[i];
+            const DgNode ny = nd[y];
+            if (!(ny.flags & DG_NF_DELETED))
+                for (uint32_t e = 0; e < ny.out_len; e++) {
+                    const uint32_t d = pool[ny.out_off + 2u * e];
+                    if (d == NT - 1u) continue;
+                    lo = d < lo ? d : lo; hi = d > hi ? d : hi;
+                }
+        }
+        const bool rec = hi > lo + 1u;
+        const unsigned long long m = __ballot(rec);
+        if (m) {
+            const uint32_t base = forb[0];
+            const uint32_t k = base + (uint32_t)__popcll(m & DG_LT(lane));
+            if (rec && k < DG_FORB_MAX) { forb[1u + 2u * k] = lo; forb[2u + 2u * k] = hi; }
+            DG_WAVE_FENCE();
+            if (lane == 0) {
+                forb[0] = base + (uint32_t)__popcll(m);
+                if (base + (uint32_t)__popcll(m) > DG_FORB_MAX) p.pro_state[4u * t + 3u] |= 2u;      // too many: no cuts
+            }
+            DG_WAVE_FENCE();
+        }
+    }
+    // the shared lists get room (3 x their length + 16) and tombstones behind their entries
+    for (int which = 0; which < 2; which++) {
+        const int v = which == 0 ? 0 : (int)NT - 1;
+        const DgNode nv = nd[v];
+        const uint32_t len = which == 0 ? nv.out_len : nv.in_len;
+        uint32_t cap = 3u * len + 16u;
+        if (cap > 65535u) cap = 65535u;
+        const uint32_t words = which == 0 ? 2u * cap : cap;
+        uint32_t off = 0;
+        if (lane == 0) {
+            off = atomicAdd(&p.pool_top[t], words);
+            if ((uint64_t)off + words > p.pool_size[t]) { dg_fail(p, DG_E_POOL_TGT); p.st->bad_target = t; off = 0xFFFFFFFFu; }
+        }
+        off = (uint32_t)DG_RL(off, 0);
+        if (off == 0xFFFFFFFFu) return;
+        const uint32_t old = which == 0 ? nv.out_off : nv.in_off;
+        const uint32_t lw = which == 0 ? 2u * len : len;
+        for (uint32_t i = lane; i < words; i += 64) {
+            uint32_t w = i < lw ? pool[old + i] : DG_TOMB;
+            if (which == 0 && i >= lw && (i & 1u)) w = 0u;         // (count word of an empty slot)
+            pool[off + i] = w;
+        }
+        if (lane == 0) {
+            if (which == 0) { nd[v].out_off = off; nd[v].out_cap = (uint16_t)cap; }
+            else { nd[v].in_off = off; nd[v].in_cap = (uint16_t)cap; }
+            p.sh_cnt[2u * t + (uint32_t)which] = len;
+        }
+    }
+}
+
+// cuts for k_merge_list: up to p.seg_max pieces per target, conditions (1) - (4) above
+__global__ __launch_bounds__(64) void k_cuts2(DgParams p) {
+    __shared__ uint32_t s_dead[2 * 256];
+    __shared__ uint32_t s_cut[72];
+    const uint32_t t = blockIdx.x;
+    if (dg_failed(p)) return;
+    const int lane = threadIdx.x;
+    uint32_t nseg = 1;
+    const bool skip = dg_tskip(p, t);
+    if (!skip) {
+        const uint32_t blen = p.tlen[t];
+        const DgNode *nd = p.nodes + p.node_base[t];
+        const uint32_t *bid = p.bid + p.bbv_base[t];
+        const int32_t *cov = p.cov + p.bbv_base[t];
+        const uint64_t ab = p.aln_begin[t];
+        const uint32_t K = (uint32_t)(p.aln_begin[t + 1] - ab);
+        const uint32_t *forb = p.forb + (uint64_t)t * (2u * DG_FORB_MAX + 1u);
+        const uint32_t nforb = forb[0] < DG_FORB_MAX ? forb[0] : DG_FORB_MAX;
+        bool allow = !(p.pro_state[4u * t + 3u] & 2u) && p.pro_state[4u * t] < p.pro_state[4u * t + 1u];
+        // (4) dead zones behind read ends, (2) the longest chain a read begins with
+        uint32_t maxlead = 0, ndead = 0;
+        for (uint32_t r0 = 0; r0 < K; r0 += 64) {
+            const uint32_t r = r0 + (uint32_t)lane;
+            uint32_t tr = 0, e = 0;
+            if (r < K) {
+                const uint32_t l = p.rd_lead[ab + r];
+                maxlead = l > maxlead ? l : maxlead;
+                tr = p.rd_trail[ab + r]; e = p.rd_e[ab + r];
+            }
+            const unsigned long long m = __ballot(tr > 0);
+            const uint32_t k = ndead + (uint32_t)__popcll(m & DG_LT(lane));
+            if (tr > 0 && k < 256u) { s_dead[2 * k] = e; s_dead[2 * k + 1] = e + tr + 1u; }
+            ndead += (uint32_t)__popcll(m);
+        }
+        for (int o = 32; o; o >>= 1) { const uint32_t x = __shfl_xor(maxlead, o); maxlead = x > maxlead ? x : maxlead; }
+        if (ndead > 256u) allow = false;
+        __syncthreads();
+        const uint32_t pmin = 2u * (maxlead + 2u);
+        uint32_t want = blen / (p.seg_min ? p.seg_min : 1u);
+        if (want > p.seg_max) want = p.seg_max;
+        if (want > 64u) want = 64u;
+        if (want < 1 || !allow) want = 1;
+        if (lane == 0) s_cut[0] = 0;
+        for (uint32_t s = 1; s < want; s++) {
+            const uint32_t p0 = 1u + (uint32_t)((uint64_t)s * blen / want);
+            const uint32_t span = blen / want / 2u;          // stays below the next ideal position
+            uint32_t found = 0;
+            for (uint32_t o = 0; o < span && !found; o += 64) {
+                const uint32_t pos = p0 + o + (uint32_t)lane;
+                uint32_t v = 0;
+                bool ok = false;
+                if (o + (uint32_t)lane < span && pos > pmin && pos <= blen) {
+                    v = bid[pos];
+                    ok = nd[v].weight - 1 == cov[pos];
+                    for (uint32_t d = 0; d < ndead && ok; d++) ok = !(pos > s_dead[2 * d] && pos <= s_dead[2 * d + 1]);
+                    for (uint32_t f = 0; f < nforb && ok; f++) ok = !(v > forb[1u + 2u * f] && v < forb[2u + 2u * f]);
+                }
+                const unsigned long long m = __ballot(ok);
+                if (m) found = (uint32_t)DG_RL(v, __ffsll((long long)m) - 1);
+            }
+            if (found) { if (lane == 0) s_cut[nseg] = found; nseg++; }
+        }
+        __syncthreads();
+    }
+    // the target's segments, in a row and in order
+    __shared__ uint32_t s_base;
+    if (lane == 0) {
+        s_base = atomicAdd(&p.tile_list[0], nseg);
+        p.wl_first[t] = s_base;
+    }
+    __syncthreads();
+    const uint32_t base = s_base;
+    for (uint32_t s = lane; s < nseg; s += 64) {
+        const uint32_t i = base + s;
+        if (i < p.tile_list_cap) {
+            p.tile_list[4 + 3 * i] = t;
+            p.tile_list[5 + 3 * i] = skip ? 0u : s_cut[s];
+            p.tile_list[6 + 3 * i] = s + 1 < nseg ? s_cut[s + 1] : DG_NOSEG_END;
+        }
+    }
+}
+
+// after every worker: tombstones out of the shared lists, then the visit of the exit vertex
+// (mergeInNodes(exit) and its recursion: the last visit of the reference's sweep)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_merge_fin(DgParams p) {
+    const uint32_t t = blockIdx.x;
+    if (dg_failed(p) || dg_tskip(p, t)) return;
+    const int lane = threadIdx.x;
+    const uint64_t nb = p.node_base[t];
+    DgNode *nd = p.nodes + nb;
+    uint32_t *pool = p.pool + p.pool_base[t];
+    const uint32_t NT = p.n_nodes[t];
+    for (int which = 0; which < 2; which++) {
+        const int v = which == 0 ? 0 : (int)NT - 1;
+        const uint32_t off = which == 0 ? nd[v].out_off : nd[v].in_off;
+        const uint32_t n = p.sh_cnt[2u * t + (uint32_t)which];
+        uint32_t w = 0;                                    // entries kept so far
+        for (uint32_t i0 = 0; i0 < n; i0 += 64) {
+            const uint32_t i = i0 + (uint32_t)lane;
+            uint32_t a = DG_TOMB, b = 0;
+            if (i < n) { a = which == 0 ? pool[off + 2u * i] : pool[off + i]; if (which == 0) b = pool[off + 2u * i + 1u]; }
+            const bool keep = a != DG_TOMB;
+            const unsigned long long m = __ballot(keep);
+            DG_WAVE_FENCE();                               // (all loads of the round before its stores: w <= i0)
+            const uint32_t k = w + (uint32_t)__popcll(m & DG_LT(lane));
+            if (keep) { if (which == 0) { pool[off + 2u * k] = a; pool[off + 2u * k + 1u] = b; } else pool[off + k] = a; }
+            w += (uint32_t)__popcll(m);
+            DG_WAVE_FENCE();
+        }
+        if (lane == 0) { if (which == 0) nd[v].out_len = (uint16_t)w; else nd[v].in_len = (uint16_t)w; }
+    }
+    DG_WAVE_FENCE();
+    if (p.pro_state[4u * t + 3u] & 1u) return;            // (a tiny target: the prologue came as far as exit)
+    dg_merge_segment<false>(p, t, (int)NT - 1, 0x7fffffff, p.stk + (uint64_t)blockIdx.x * p.stk_words, DG_MM_FINISH);
 }
 

@@ -31,14 +31,14 @@ exp = oracle_batch(small, 6, 500, 50)
 part = synth.make_batch(6, 0, 24, seed=32000, min_span=0.5, tlens=np.array([5000, 7000, 9000, 3000, 12000, 6000]))
 exp_p = oracle_batch(part, 6, 500, 10)
 big = synth.make_batch(1000, 10000, 40, seed=1000)
-modes = [("0", None), ("1", None), ("1", "16"), ("1", "64")]
+# mode = "<tiles>:<gcuts>"
+modes = [("0", "0"), ("0", "1")]
 if len(sys.argv) > 1:
-    modes = [tuple(a.split(":")) if ":" in a else (a, None) for a in sys.argv[1:]]
-for mode, pos in modes:
+    modes = [tuple(a.split(":")) for a in sys.argv[1:]]
+for mode, gc in modes:
     os.environ["DAGCON_TILES"] = mode
-    if pos: os.environ["DAGCON_TILE_POS"] = pos
-    else: os.environ.pop("DAGCON_TILE_POS", None)
-    print("---- tiles", mode, "pos", pos, flush=True)
+    os.environ["DAGCON_GCUTS"] = gc
+    print("---- tiles", mode, "gcuts", gc, flush=True)
     r = timed("adv", adv, 1, min_cov=0, min_len=0, trim=0, min_weight=0)
     print("  parity adv:", r == exp_adv, flush=True)
     r = timed("small", small, 1, min_cov=6, min_len=500, trim=50)
@@ -46,5 +46,5 @@ for mode, pos in modes:
     r = timed("part", part, 1, min_cov=6, min_len=500, trim=10)
     print("  parity part:", r == exp_p, flush=True)
     rb = timed("configs[1]", big, 3, min_cov=6, min_len=500, trim=50)
-    if mode == "0": ref = rb
+    if (mode, gc) == ("0", "0"): ref = rb
     else: print("  same as wave kernel:", rb == ref, flush=True)
