@@ -64,12 +64,13 @@ struct Ctx {
     DevBuf d_node_base, d_n_nodes, d_pool_base, d_pool_size, d_pool_top, d_t_nins;
     DevBuf d_matA, d_matD, d_matC, d_cov, d_gcount, d_gbase, d_bid;
     DevBuf d_nodes, d_best, d_queue, d_score, d_cns_tmp, d_bp_tt;
-    DevBuf d_pool, d_stk, d_cuts, d_cuts_bp, d_bp_stat, d_bp_len, d_nextcut, d_tile_list, d_rd, d_pro_state, d_forb, d_sh_cnt, d_seg_done, d_wl_first, d_queue0;
+    DevBuf d_pool, d_stk, d_cuts, d_cuts_bp, d_bp_stat, d_bp_len, d_nextcut, d_tile_list, d_rd, d_pro_state, d_sh_cnt, d_seg_done, d_wl_first, d_queue0;
     DevBuf d_al[12];                                // dagcon_align: blobs, offsets, outputs, directions
     DevBuf d_cns, d_cns_off, d_cns_len, d_seg_first, d_n_seg, d_seg_r0, d_seg_r1, d_st;
 
     uint64_t norm_cap = 0, node_cap = 0, pool_cap = 0, cns_cap = 0, seg_cap = 0;
     uint32_t stk_words = 4096, growth_pct = 100, seg_max = 8, bp_max = 16, seg_env = 0;    // (scratch per target and segment: grown x4 and re-run on DG_E_STACK)
+    uint32_t sh_log = 16;                           // slots per segment behind enter's / exit's list (x2 on DG_E_LOG_OVF)
     uint32_t gcuts = 1;                             // partial-span cuts: prologue + worklist + epilogue (DAGCON_GCUTS=0: off)
     uint32_t tile_pos = 0, tile_words = 0, tile_ny = 0, tile_list_cap = 0, list_grid = 8192;   // LDS tiles (tile_pos 0: off)
     double ins_per_pos = -1.0;                      // inserted vertices per backbone position, from the last run
@@ -157,9 +158,8 @@ int ensure_arenas(Ctx *c) {
     if (c->gcuts) {
         ENSURE(c, c->d_rd, (uint64_t)c->A * 16 + 16);
         ENSURE(c, c->d_pro_state, (uint64_t)c->T * 16 + 16);
-        ENSURE(c, c->d_forb, (uint64_t)c->T * (2 * DG_FORB_MAX + 1) * 4 + 16);
-        ENSURE(c, c->d_sh_cnt, (uint64_t)c->T * 8 + 16);
-        ENSURE(c, c->d_seg_done, (uint64_t)c->tile_list_cap * 4 + 16);
+        ENSURE(c, c->d_sh_cnt, (uint64_t)c->T * (2 + 2 * DG_SH_MAX) * 4 + 16);
+        ENSURE(c, c->d_seg_done, (uint64_t)c->tile_list_cap * (DG_SH_MAX + 1) * 4 + 16);
         ENSURE(c, c->d_wl_first, (uint64_t)c->T * 4 + 16);
         ENSURE(c, c->d_queue0, c->node_cap * 4);
     }
@@ -222,9 +222,9 @@ void fill_params(Ctx *c, DgParams &p) {
     // workers hide each other's latency and it only takes issue slots from them
     { const char *e = getenv("DAGCON_PF_AHEAD"); p.pf_ahead = e ? (uint32_t)atoi(e) : (c->expected_workers >= 4096 ? 0u : 48u); }
     p.seg_max = c->seg_max; p.seg_min = c->opts.min_segment_len ? c->opts.min_segment_len : 768u; p.cuts = (uint32_t *)c->d_cuts.p; p.bp_max = c->bp_max; p.cuts_bp = (uint32_t *)c->d_cuts_bp.p; p.bp_stat = (float *)c->d_bp_stat.p; p.bp_len = (uint32_t *)c->d_bp_len.p;
-    p.gcuts = c->gcuts;
+    p.gcuts = c->gcuts; p.sh_log = c->sh_log;
     p.rd_s = (uint32_t *)c->d_rd.p; p.rd_e = p.rd_s + c->A; p.rd_lead = p.rd_e + c->A; p.rd_trail = p.rd_lead + c->A;
-    p.pro_state = (uint32_t *)c->d_pro_state.p; p.forb = (uint32_t *)c->d_forb.p; p.sh_cnt = (uint32_t *)c->d_sh_cnt.p;
+    p.pro_state = (uint32_t *)c->d_pro_state.p; p.sh_cnt = (uint32_t *)c->d_sh_cnt.p;
     p.queue0 = (int32_t *)c->d_queue0.p;
     p.seg_done = (uint32_t *)c->d_seg_done.p; p.wl_first = (uint32_t *)c->d_wl_first.p;
     p.nextcut = (uint32_t *)c->d_nextcut.p; p.tile_pos = c->tile_pos; p.tile_words = c->tile_words;
@@ -284,7 +284,7 @@ int launch_all(Ctx *c) {
         if (c->gcuts && !c->tile_pos) {
             // partial-span cuts: enter and what hangs on it first, then the segments as a worklist, exit last
             HIPCHK(c, hipMemsetAsync(c->d_tile_list.p, 0, 16, s));
-            HIPCHK(c, hipMemsetAsync(c->d_seg_done.p, 0, (size_t)c->tile_list_cap * 4, s));
+            HIPCHK(c, hipMemsetAsync(c->d_seg_done.p, 0, (size_t)c->tile_list_cap * (DG_SH_MAX + 1) * 4, s));
             hipLaunchKernelGGL(k_merge_pro, dim3(c->T), dim3(64), 0, s, p);
             hipLaunchKernelGGL(k_cuts2, dim3(c->T), dim3(64), 0, s, p);
             hipLaunchKernelGGL(k_merge_list, dim3(c->list_grid), dim3(64), 0, s, p);
@@ -375,7 +375,7 @@ void dagcon_destroy(dagcon_ctx *ctx) {
                      &c->d_n_ins, &c->d_n_del, &c->d_norm, &c->d_node_base, &c->d_n_nodes,
                      &c->d_pool_base, &c->d_pool_size, &c->d_pool_top, &c->d_t_nins, &c->d_matA, &c->d_matD,
                      &c->d_matC, &c->d_cov, &c->d_gcount, &c->d_gbase, &c->d_bid, &c->d_nodes,
-                     &c->d_best, &c->d_queue, &c->d_score, &c->d_cns_tmp, &c->d_bp_tt, &c->d_pool, &c->d_stk, &c->d_cuts, &c->d_cuts_bp, &c->d_bp_stat, &c->d_bp_len, &c->d_nextcut, &c->d_tile_list, &c->d_rd, &c->d_pro_state, &c->d_forb, &c->d_sh_cnt, &c->d_seg_done, &c->d_wl_first, &c->d_queue0, &c->d_cns,
+                     &c->d_best, &c->d_queue, &c->d_score, &c->d_cns_tmp, &c->d_bp_tt, &c->d_pool, &c->d_stk, &c->d_cuts, &c->d_cuts_bp, &c->d_bp_stat, &c->d_bp_len, &c->d_nextcut, &c->d_tile_list, &c->d_rd, &c->d_pro_state, &c->d_sh_cnt, &c->d_seg_done, &c->d_wl_first, &c->d_queue0, &c->d_cns,
                      &c->d_cns_off, &c->d_cns_len, &c->d_seg_first, &c->d_n_seg, &c->d_seg_r0, &c->d_seg_r1,
                      &c->d_st};
     for (DevBuf *b : all) free_buf(*b);
@@ -637,6 +637,7 @@ int dagcon_fetch(dagcon_ctx *ctx, dagcon_results *res) {
         if (f & DG_E_POOL_TGT) c->growth_pct *= 3;
         if (f & DG_E_STACK) c->stk_words *= 4;
         if (f & DG_E_LIST_OVF) c->tile_list_cap *= 4;
+        if (f & DG_E_LOG_OVF) c->sh_log *= 2;
         if (f & DG_E_OUT_OVF) {
             c->cns_cap = std::max<uint64_t>(c->cns_cap, c->h_st.cns_top + 1024);
             c->seg_cap = std::max<uint64_t>(c->seg_cap, c->h_st.seg_top + 1024);

@@ -35,6 +35,7 @@
 #define DG_E_INTERNAL    0x080u  // invariant violated (empty list dereference, list > 65535)
 #define DG_E_OUT_OVF     0x100u  // output arena too small
 #define DG_E_TOO_BIG     0x200u  // a target has more than 2^25-2 vertices
+#define DG_E_LOG_OVF     0x800u  // a segment appended more entries to enter's / exit's list than its slots hold (rerun with more)
 #define DG_E_LIST_OVF    0x400u  // more tiles handed to k_merge_list than its list holds (rerun with a longer one)
 
 // failures of one target (its input, or an invariant of its graph): recorded in DgParams::tfail,
@@ -73,6 +74,7 @@ struct __attribute__((aligned(16))) DgNode {
 };
 #define DG_NF_BACKBONE 1u
 #define DG_NF_DELETED  2u
+#define DG_NF_SHARED   4u   // during k_merge_list: a list of this vertex is shared by the segments' workers (DgGraph::sh)
 
 // arrival cell: (target base << 25) | (source id + 1); deletion: id field all ones
 #define DG_CELL_ID(c)   ((c) & 0x1FFFFFFu)
@@ -81,7 +83,7 @@ struct __attribute__((aligned(16))) DgNode {
 #define DG_MAX_NODES    0x1FFFFFDu
 #define DG_EMIT_SEG     512u   // backbone positions per k_emit wave: default of DgParams::emit_shift (1 << 9)
 #define DG_CK_NONE      0xFFFFFFFFu
-#define DG_FORB_MAX     64u
+#define DG_SH_MAX       8u            // shared out-lists per target (enter + vertices of the prologue that reach into several segments)
 #define DG_TOMB         0xFFFFFFFFu   // erased entry of a shared list (enter's out-list, exit's in-list)
 
 struct DgParams {
@@ -171,9 +173,9 @@ struct DgParams {
     int32_t *queue0;               // FIFO of the prologue and of the segment that resumes it (it also holds the vertices
                                    // the prologue visits beyond that segment: a stretch of `queue` would be too short)
     uint32_t *pro_state;           // [T][4]: queue head, queue tail of the prologue, vertices it visited, 1 = no cuts allowed
-    uint32_t *forb;                // [T][2 * DG_FORB_MAX + 1]: count, then (lo, hi) vertex id pairs no cut may lie strictly inside
-    uint32_t *sh_cnt;              // [T][2]: physical entries of enter's out-list / exit's in-list (shared lists)
-    uint32_t *seg_done;            // [tile_list_cap]: 1 = the worklist entry has finished
+    uint32_t *sh_cnt;              // [T][2 + 2 * DG_SH_MAX]: shared out-lists n, entries of in[exit], then n x (vertex, entries of its out-list)
+    uint32_t *seg_done;            // [tile_list_cap][DG_SH_MAX + 1]: slots of its stretches a worklist entry has used (last: in[exit])
+    uint32_t sh_log;               // slots a segment has behind either shared list
     uint32_t *wl_first;            // [T]: worklist index of the target's first segment
     // ---- LDS tiles (k_cutmap, k_merge_tile, k_merge_list) ----
     uint32_t *nextcut;             // [bbv_base + p]: smallest cut position >= p (k_cutmap)

@@ -50,21 +50,26 @@ struct DgGraph {
     bool err;
     // Partial-span pileups (k_cuts2): reads that start or end inside the target put enter -> x and
     // x -> exit edges across the cut vertices, so enter's out-list and exit's in-list are touched by
-    // every segment's worker.  Entries of such a list belong to the segment of the vertex they name,
+    // every segment's worker, and so are the out-lists of the few vertices the prologue has visited
+    // whose out-edges lead into more than one segment (insertion chains that reads begin with, united
+    // by mergeOutNodes(enter) wherever on the backbone they lead): the vertices flagged DG_NF_SHARED.
+    // Entries of such a list belong to the segment of the vertex they name,
     // and a worker only ever looks for, changes or erases entries of its own segment; what the
     // reference's order fixes is the ORDER OF APPENDS, and all visits of segment i precede all visits
     // of segment i + 1 in the reference's FIFO (the cut argument above k_cuts).  Hence the protocol
-    // (sh != 0): an erase leaves a tombstone (nobody's entries move), an append waits until every
-    // earlier segment of the target has finished and then takes the next slot from an atomic cursor
-    // (the slack behind the list is tombstones, put there by the prologue), and k_merge_fin squeezes the
-    // tombstones out before it visits the exit vertex.  Neither vertex can be a member of a merge group
-    // ('^' and '$' are nobody else's base).
+    // (sh != 0): an erase leaves a tombstone (nobody's entries move); an append goes to the worker's
+    // own stretch of slots behind the list -- k_cuts2 lays the list out as [entries][slots of segment 0]
+    // [slots of segment 1] ..., all tombstones to begin with -- so appends need no waiting and stand in
+    // segment order, each segment's in its own order; k_merge_fin squeezes the tombstones out before it
+    // visits the exit vertex.  No shared vertex can be a member of a merge group ('^' and '$' are nobody
+    // else's base; a vertex with out-edges into two segments has more than one out-edge whatever is
+    // merged, since no worker ever removes the last entry that points into its own segment).
     int sh;                        // 1: the protocol is on (workers of k_merge_list)
     int X;                         // the exit vertex
-    uint32_t *sh_cnt;              // [0] physical entries of out[enter], [1] of in[exit]
-    uint32_t *done;                // DgParams::seg_done
-    uint32_t wait_lo, wait_hi;     // worklist entries of the earlier segments of this target
-    bool waited;
+    const uint32_t *sh_tab;        // this target's row of DgParams::sh_cnt
+    uint32_t seg;                  // index of the worker's segment in its target
+    uint32_t lg_cap;               // slots per stretch
+    uint32_t *lg_cnt;              // [DG_SH_MAX + 1] slots of its stretches this worker has used
 };
 
 __device__ __forceinline__ void dgg_fail(DgGraph &g, uint32_t bit) {
@@ -93,38 +98,45 @@ __device__ __forceinline__ void dgw_fail(DgGraph &g, uint32_t bit, int lane) {
     } while (0)
 
 // ---- ordered slot lists (single lane) --------------------------------------
-#define DGG_SH_OUT(g, v) ((g).sh && (v) == 0)
 #define DGG_SH_IN(g, v) ((g).sh && (v) == (g).X)
-// appends to a shared list come in segment order: wait for the earlier segments of the target
-__device__ inline void dgg_wait_pred(DgGraph &g) {
-    if (g.waited) return;
-    for (uint32_t i = g.wait_lo; i < g.wait_hi && !g.err; i++) {
-        unsigned spins = 0;
-        while (atomicAdd(&g.done[i], 0u) == 0u) {
-            __builtin_amdgcn_s_sleep(16);
-            if (++spins > (1u << 23)) { dgg_fail(g, DG_E_INTERNAL); break; }      // (every spin is bounded)
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    g.waited = true;
+// index of v among the target's shared out-lists, -1 if out[v] is v's own business
+__device__ inline int dgg_sh_out(const DgGraph &g, int v) {
+    if (!g.sh || !(g.nd[v].flags & DG_NF_SHARED) || v == g.X) return -1;
+    const uint32_t n = g.sh_tab[0];
+    for (uint32_t i = 0; i < n; i++)
+        if ((int)g.sh_tab[2u + 2u * i] == v) return (int)i;
+    return -1;
 }
+#define DGG_SH_BASE_OUT(g, i) ((g).sh_tab[3u + 2u * (uint32_t)(i)])
+#define DGG_SH_BASE_IN(g) ((g).sh_tab[1])
 __device__ inline int dgg_out_find(DgGraph &g, int v, int dst) {
     const uint32_t off = g.nd[v].out_off;
-    const int n = DGG_SH_OUT(g, v) ? (int)atomicAdd(&g.sh_cnt[0], 0u) : (int)g.nd[v].out_len;
+    const int si = dgg_sh_out(g, v);
+    const int n = si >= 0 ? (int)DGG_SH_BASE_OUT(g, si) : (int)g.nd[v].out_len;
     for (int i = 0; i < n; i++)
         if ((int)g.pool[off + 2 * i] == dst) return i;
+    if (si >= 0) {                                         // ... and what this worker has appended
+        const uint32_t lo = (uint32_t)n + g.seg * g.lg_cap;
+        for (uint32_t i = lo, e = lo + g.lg_cnt[si]; i < e; i++)
+            if ((int)g.pool[off + 2 * i] == dst) return (int)i;
+    }
     return -1;
 }
 __device__ inline int dgg_in_find(DgGraph &g, int v, int src) {
     const uint32_t off = g.nd[v].in_off;
-    const int n = DGG_SH_IN(g, v) ? (int)atomicAdd(&g.sh_cnt[1], 0u) : (int)g.nd[v].in_len;
+    const int n = DGG_SH_IN(g, v) ? (int)DGG_SH_BASE_IN(g) : (int)g.nd[v].in_len;
     for (int i = 0; i < n; i++)
         if ((int)g.pool[off + i] == src) return i;
+    if (DGG_SH_IN(g, v)) {
+        const uint32_t lo = (uint32_t)n + g.seg * g.lg_cap;
+        for (uint32_t i = lo, e = lo + g.lg_cnt[DG_SH_MAX]; i < e; i++)
+            if ((int)g.pool[off + i] == src) return (int)i;
+    }
     return -1;
 }
 __device__ inline void dgg_out_erase(DgGraph &g, int v, int idx) {
     const uint32_t off = g.nd[v].out_off;
-    if (DGG_SH_OUT(g, v)) { g.pool[off + 2 * idx] = DG_TOMB; g.pool[off + 2 * idx + 1] = 0u; return; }
+    if (dgg_sh_out(g, v) >= 0) { g.pool[off + 2 * idx] = DG_TOMB; g.pool[off + 2 * idx + 1] = 0u; return; }
     const int n = g.nd[v].out_len;
     for (int i = idx; i + 1 < n; i++) {
         g.pool[off + 2 * i] = g.pool[off + 2 * i + 2];
@@ -146,12 +158,13 @@ __device__ inline uint32_t dgg_alloc(DgGraph &g, uint32_t words) {
 }
 __device__ inline void dgg_out_append(DgGraph &g, int v, int dst, int count) {
     uint32_t off = g.nd[v].out_off;
-    if (DGG_SH_OUT(g, v)) {
-        dgg_wait_pred(g);
-        if (g.err) return;
-        const uint32_t i = atomicAdd(&g.sh_cnt[0], 1u);
-        if (i >= g.nd[v].out_cap) { dgg_fail(g, DG_E_POOL_TGT); return; }     // (re-run with more slack)
+    const int si = dgg_sh_out(g, v);
+    if (si >= 0) {
+        const uint32_t k = g.lg_cnt[si];
+        if (k >= g.lg_cap) { dgg_fail(g, DG_E_LOG_OVF); return; }               // (re-run with longer stretches)
+        const uint32_t i = DGG_SH_BASE_OUT(g, si) + g.seg * g.lg_cap + k;
         g.pool[off + 2 * i] = (uint32_t)dst; g.pool[off + 2 * i + 1] = (uint32_t)count;
+        g.lg_cnt[si] = k + 1u;
         return;
     }
     const int n = g.nd[v].out_len;
@@ -172,11 +185,10 @@ __device__ inline void dgg_out_append(DgGraph &g, int v, int dst, int count) {
 __device__ inline void dgg_in_append(DgGraph &g, int v, int src) {
     uint32_t off = g.nd[v].in_off;
     if (DGG_SH_IN(g, v)) {
-        dgg_wait_pred(g);
-        if (g.err) return;
-        const uint32_t i = atomicAdd(&g.sh_cnt[1], 1u);
-        if (i >= g.nd[v].in_cap) { dgg_fail(g, DG_E_POOL_TGT); return; }
-        g.pool[off + i] = (uint32_t)src;
+        const uint32_t k = g.lg_cnt[DG_SH_MAX];
+        if (k >= g.lg_cap) { dgg_fail(g, DG_E_LOG_OVF); return; }
+        g.pool[off + DGG_SH_BASE_IN(g) + g.seg * g.lg_cap + k] = (uint32_t)src;
+        g.lg_cnt[DG_SH_MAX] = k + 1u;
         return;
     }
     const int n = g.nd[v].in_len;
@@ -221,7 +233,7 @@ __device__ inline int dgg_push_in_frame(DgGraph &g, int sp, int fp, int n) {
     int nc = 0;
     for (int i = 0; i < len; i++) {
         const int s = (int)g.pool[off + i];
-        if (g.nd[s].out_len == 1 && !DGG_SH_OUT(g, s)) nc++;
+        if (g.nd[s].out_len == 1 && !(g.sh && (g.nd[s].flags & DG_NF_SHARED))) nc++;
     }
     if (nc < 2) return -1;
     if ((uint32_t)(sp + 3 + 2 * nc) > g.stk_words) { dgg_fail(g, DG_E_STACK); return -1; }
@@ -229,7 +241,7 @@ __device__ inline int dgg_push_in_frame(DgGraph &g, int sp, int fp, int n) {
     int k = 0;
     for (int i = 0; i < len; i++) {
         const int s = (int)g.pool[off + i];
-        if (g.nd[s].out_len == 1 && !DGG_SH_OUT(g, s)) { g.stk[sp + 3 + k] = s; g.stk[sp + 3 + nc + k] = g.nd[s].base; k++; }
+        if (g.nd[s].out_len == 1 && !(g.sh && (g.nd[s].flags & DG_NF_SHARED))) { g.stk[sp + 3 + k] = s; g.stk[sp + 3 + nc + k] = g.nd[s].base; k++; }
     }
     return sp + 3 + 2 * nc;
 }
@@ -560,7 +572,7 @@ __device__ inline bool dgw_merge_out_group(DgGraph &g, int u, const DgNode &nu, 
     uint4 hn2 = make_uint4(0, 0, 0, 0);
     if (vic_entry) hn2 = dg_lo16(&DG_NV(g, n2));
     if (__ballot(vic_entry && DG_H_INLEN(hn2) > 64)) return false;
-    if (g.sh && __ballot(vic_entry && n2 == g.X)) return false;      // in[exit] is shared: literal path
+    if (g.sh && __ballot(vic_entry && ((hn2.y >> 8) & DG_NF_SHARED))) return false;      // in[exit] is shared: literal path
 
     // ---- nothing has been modified up to here ----
     // :236-243 count(u->an) += counts of u->victims, weight[an] += weights
@@ -666,7 +678,7 @@ __device__ inline bool dgw_merge_in_group(DgGraph &g, int n, const DgNode &nn, u
     uint4 hn1 = make_uint4(0, 0, 0, 0);
     if (fl) hn1 = dg_lo16(&DG_NV(g, n1));
     if (__ballot(fl && DG_H_OUTLEN(hn1) > 64)) return false;
-    if (g.sh && __ballot(fl && n1 == 0)) return false;                // out[enter] is shared: literal path
+    if (g.sh && __ballot(fl && ((hn1.y >> 8) & DG_NF_SHARED))) return false;    // a shared out-list: literal path
 
     // ---- nothing has been modified up to here ----
     // :183-190 survivor's out edge count and weight
@@ -848,8 +860,9 @@ __device__ __forceinline__ void dg_merge_segment(const DgParams &p, const uint32
     g.stk = stk_base; g.stk_words = p.stk_words;
     g.st = p.st; g.tfail = p.tfail + t; g.t = t; g.err = false;
     const bool sh = p.gcuts && mode == DG_MM_WORKER;
-    g.sh = sh ? 1 : 0; g.X = (int)NT - 1; g.sh_cnt = p.sh_cnt + 2u * t; g.done = p.seg_done;
-    g.wait_lo = wlo; g.wait_hi = me; g.waited = false;
+    g.sh = sh ? 1 : 0; g.X = (int)NT - 1;
+    g.sh_tab = p.sh_cnt + (uint64_t)t * (2u + 2u * DG_SH_MAX); g.seg = me - wlo;
+    g.lg_cap = p.sh_log; g.lg_cnt = p.seg_done + (uint64_t)me * (DG_SH_MAX + 1u);
     const int X = sh ? (int)NT - 1 : -1;                               // exit, where it must be left alone
     const uint32_t N = own_q ? NT : (uint32_t)(c_hi - c_start + 1);     // vertices this worker can dequeue
     __shared__ int s_stk[2 * DG_IN_STACK];
@@ -934,7 +947,7 @@ __device__ __forceinline__ void dg_merge_segment(const DgParams &p, const uint32
                 // in lanes: out_len == 1 (low half of h.x), out lanes: in_len == 1 (high half); with shared
                 // enter / exit neither is a candidate ('^' / '$' are nobody else's base) and a visit next to
                 // them goes the literal way, where their lists are handled by the protocol
-                const bool shn = sh && valid && (is_in ? nbr == 0 : nbr == X);
+                const bool shn = sh && valid && ((h.y >> 8) & DG_NF_SHARED);
                 adj = __ballot(shn) ? 1 : 0;
                 if (adj) goto generic;
                 const unsigned long long cand = __ballot(((h.x >> (is_in ? 0u : 16u)) & 0xffffu) == 1u);
@@ -1017,7 +1030,7 @@ __device__ __forceinline__ void dg_merge_segment(const DgParams &p, const uint32
             // long lists: look for the shared vertices among u's neighbours
             const DgNode nq = DG_NV(g, u);
             bool f = false;
-            if (!skip_in) for (int i = lane; i < nq.in_len; i += 64) f |= DG_PW(g, nq.in_off + i) == 0u;
+            if (!skip_in) for (int i = lane; i < nq.in_len; i += 64) f |= (DG_NV(g, DG_PW(g, nq.in_off + i)).flags & DG_NF_SHARED) != 0;
             if (!in_only) for (int i = lane; i < nq.out_len; i += 64) f |= (int)DG_PW(g, nq.out_off + 2 * i) == X;
             adj = __ballot(f) ? 1 : 0;
         }
@@ -1030,7 +1043,7 @@ __device__ __forceinline__ void dg_merge_segment(const DgParams &p, const uint32
             if (valid) s = (int)DG_PW(g, nn.in_off + lane);
             uint4 h = make_uint4(0, 0, 0, 0);
             if (valid) h = dg_lo16(&DG_NV(g, s));
-            const unsigned long long cand = __ballot(valid && DG_H_OUTLEN(h) == 1 && !(sh && s == 0));
+            const unsigned long long cand = __ballot(valid && DG_H_OUTLEN(h) == 1 && !(sh && ((h.y >> 8) & DG_NF_SHARED)));
             unsigned long long M = 0;
             int b = 256;
             if (__popcll(cand) >= 2) b = dg_pick_group(cand, DG_H_BASE(h), fr_last, lane, &M);
@@ -1150,11 +1163,6 @@ __device__ __forceinline__ void dg_merge_segment(const DgParams &p, const uint32
     if (mode == DG_MM_PROLOGUE && lane == 0) {
         p.pro_state[4u * t] = qh; p.pro_state[4u * t + 1u] = qt; p.pro_state[4u * t + 2u] = qh;
     }
-    if (sh) {
-        // this segment's appends to the shared lists are over: the next segment may append
-        __threadfence();
-        if (lane == 0) atomicExch(&p.seg_done[me], 1u);
-    }
 #ifdef DG_STAMPS
     if (t == 0 && c_start == 0 && lane == 0) { p.st->dbg[0] = n_fast; p.st->dbg[1] = n_slow; p.st->dbg[2] = c_fast; p.st->dbg[3] = c_slow; p.st->dbg[4] = n_scalar; p.st->dbg[5] = c_a; p.st->dbg[6] = c_b; p.st->dbg[7] = c_c; p.st->dbg[8] = c_grp; p.st->dbg[9] = ng_in; p.st->dbg[10] = ng_out; p.st->dbg[11] = c_odd; p.st->dbg[12] = q_a; p.st->dbg[13] = q_b; p.st->dbg[14] = q_c; p.st->dbg[15] = q_d; }
 #endif
@@ -1176,7 +1184,6 @@ __global__ __launch_bounds__(PF ? 128 : 64) __attribute__((amdgpu_waves_per_eu(8
 // A worklist of segments (p.tile_list: [0] = entries, [2] = ticket cursor, then (target, first vertex,
 // last vertex or DG_NOSEG_END) triples, a target's segments in a row and in order): one wave per
 // entry.  Entries are taken by ticket, so a worker that waits for the earlier segments of its target
-// (dgg_wait_pred) waits for waves that are running or done, whatever the size of the grid.
 #define DG_NOSEG_END 0xFFFFFFFFu
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_merge_list(DgParams p) {
     if (dg_failed(p)) return;
@@ -1189,10 +1196,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
         const uint32_t t = p.tile_list[4 + 3 * i];
         const int c_start = (int)p.tile_list[5 + 3 * i];
         const uint32_t ce = p.tile_list[6 + 3 * i];
-        if (dg_tskip(p, t)) {
-            if (p.gcuts && threadIdx.x == 0) atomicExch(&p.seg_done[i], 1u);
-            continue;
-        }
+        if (dg_tskip(p, t)) continue;
         dg_merge_segment<false>(p, t, c_start, ce == DG_NOSEG_END ? 0x7fffffff : (int)ce, p.stk + (uint64_t)blockIdx.x * p.stk_words,
                                 DG_MM_WORKER, i, p.gcuts ? p.wl_first[t] : 0u);
         if (threadIdx.x == 0) atomicAdd(&p.st->n_mseg, 1u);
@@ -1213,8 +1217,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
 //       before anything behind v: the FIFO works level by level (level = longest path from enter), such a
 //       chain ends at level `lead` at the latest and v's level is at least p, so k_merge_pro visits levels
 //       0 .. maxlead + 1 first (that IS the reference's order) and cuts lie at p > 2 (maxlead + 2);
-//   (3) no vertex k_merge_pro has visited has out-edges on both sides of v (else two workers would rewrite
-//       one out-list): k_merge_pro records those id ranges, no cut lies inside one;
+//   (3) a vertex k_merge_pro has visited and whose out-edges lead to both sides of v has its out-list
+//       rewritten by two workers: such lists are shared like enter's (k_cuts2 finds them);
 //   (4) the dead ends in front of v (the insertion run a read ends with leads to exit only) are done before
 //       v: a read that ends at e < p with a trailing run of r vertices needs p - e > r + 1;
 // and the two vertices every segment touches, enter (out-list) and exit (in-list), follow the protocol
@@ -1230,74 +1234,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     uint32_t maxlead = 0;
     for (uint32_t r = lane; r < K; r += 64) { const uint32_t l = p.rd_lead[ab + r]; maxlead = l > maxlead ? l : maxlead; }
     for (int o = 32; o; o >>= 1) { const uint32_t x = __shfl_xor(maxlead, o); maxlead = x > maxlead ? x : maxlead; }
-    if (lane == 0) { p.pro_state[4u * t + 3u] = 0u; p.forb[(uint64_t)t * (2u * DG_FORB_MAX + 1u)] = 0u; }
+    if (lane == 0) p.pro_state[4u * t + 3u] = 0u;
     DG_WAVE_FENCE();
     dg_merge_segment<false>(p, t, 0, 0x7fffffff, p.stk + (uint64_t)blockIdx.x * p.stk_words, DG_MM_PROLOGUE, 0, 0, (int)maxlead + 1);
-    DG_WAVE_FENCE();
-    if (dg_tskip(p, t)) return;
-    const uint64_t nb = p.node_base[t];
-    DgNode *nd = p.nodes + nb;
-    uint32_t *pool = p.pool + p.pool_base[t];
-    const int32_t *queue = p.queue0 + nb;
-    const uint32_t NT = p.n_nodes[t];
-    const uint32_t nvis = p.pro_state[4u * t + 2u];
-    // (3): out-lists of the visited vertices (enter aside) that reach over more than their own neighbourhood
-    uint32_t *forb = p.forb + (uint64_t)t * (2u * DG_FORB_MAX + 1u);
-    for (uint32_t i0 = 1; i0 < nvis; i0 += 64) {
-        const uint32_t i = i0 + (uint32_t)lane;
-        uint32_t lo = 0xFFFFFFFFu, hi = 0;
-        if (i < nvis) {
-            const int y = queue[i];
-            const DgNode ny = nd[y];
-            if (!(ny.flags & DG_NF_DELETED))
-                for (uint32_t e = 0; e < ny.out_len; e++) {
-                    const uint32_t d = pool[ny.out_off + 2u * e];
-                    if (d == NT - 1u) continue;
-                    lo = d < lo ? d : lo; hi = d > hi ? d : hi;
-                }
-        }
-        const bool rec = hi > lo + 1u;
-        const unsigned long long m = __ballot(rec);
-        if (m) {
-            const uint32_t base = forb[0];
-            const uint32_t k = base + (uint32_t)__popcll(m & DG_LT(lane));
-            if (rec && k < DG_FORB_MAX) { forb[1u + 2u * k] = lo; forb[2u + 2u * k] = hi; }
-            DG_WAVE_FENCE();
-            if (lane == 0) {
-                forb[0] = base + (uint32_t)__popcll(m);
-                if (base + (uint32_t)__popcll(m) > DG_FORB_MAX) p.pro_state[4u * t + 3u] |= 2u;      // too many: no cuts
-            }
-            DG_WAVE_FENCE();
-        }
-    }
-    // the shared lists get room (3 x their length + 16) and tombstones behind their entries
-    for (int which = 0; which < 2; which++) {
-        const int v = which == 0 ? 0 : (int)NT - 1;
-        const DgNode nv = nd[v];
-        const uint32_t len = which == 0 ? nv.out_len : nv.in_len;
-        uint32_t cap = 3u * len + 16u;
-        if (cap > 65535u) cap = 65535u;
-        const uint32_t words = which == 0 ? 2u * cap : cap;
-        uint32_t off = 0;
-        if (lane == 0) {
-            off = atomicAdd(&p.pool_top[t], words);
-            if ((uint64_t)off + words > p.pool_size[t]) { dg_fail(p, DG_E_POOL_TGT); p.st->bad_target = t; off = 0xFFFFFFFFu; }
-        }
-        off = (uint32_t)DG_RL(off, 0);
-        if (off == 0xFFFFFFFFu) return;
-        const uint32_t old = which == 0 ? nv.out_off : nv.in_off;
-        const uint32_t lw = which == 0 ? 2u * len : len;
-        for (uint32_t i = lane; i < words; i += 64) {
-            uint32_t w = i < lw ? pool[old + i] : DG_TOMB;
-            if (which == 0 && i >= lw && (i & 1u)) w = 0u;         // (count word of an empty slot)
-            pool[off + i] = w;
-        }
-        if (lane == 0) {
-            if (which == 0) { nd[v].out_off = off; nd[v].out_cap = (uint16_t)cap; }
-            else { nd[v].in_off = off; nd[v].in_cap = (uint16_t)cap; }
-            p.sh_cnt[2u * t + (uint32_t)which] = len;
-        }
-    }
 }
 
 // cuts for k_merge_list: up to p.seg_max pieces per target, conditions (1) - (4) above
@@ -1316,9 +1255,7 @@ __global__ __launch_bounds__(64) void k_cuts2(DgParams p) {
         const int32_t *cov = p.cov + p.bbv_base[t];
         const uint64_t ab = p.aln_begin[t];
         const uint32_t K = (uint32_t)(p.aln_begin[t + 1] - ab);
-        const uint32_t *forb = p.forb + (uint64_t)t * (2u * DG_FORB_MAX + 1u);
-        const uint32_t nforb = forb[0] < DG_FORB_MAX ? forb[0] : DG_FORB_MAX;
-        bool allow = !(p.pro_state[4u * t + 3u] & 2u) && p.pro_state[4u * t] < p.pro_state[4u * t + 1u];
+        bool allow = p.pro_state[4u * t] < p.pro_state[4u * t + 1u];
         // (4) dead zones behind read ends, (2) the longest chain a read begins with
         uint32_t maxlead = 0, ndead = 0;
         for (uint32_t r0 = 0; r0 < K; r0 += 64) {
@@ -1355,7 +1292,6 @@ __global__ __launch_bounds__(64) void k_cuts2(DgParams p) {
                     v = bid[pos];
                     ok = nd[v].weight - 1 == cov[pos];
                     for (uint32_t d = 0; d < ndead && ok; d++) ok = !(pos > s_dead[2 * d] && pos <= s_dead[2 * d + 1]);
-                    for (uint32_t f = 0; f < nforb && ok; f++) ok = !(v > forb[1u + 2u * f] && v < forb[2u + 2u * f]);
                 }
                 const unsigned long long m = __ballot(ok);
                 if (m) found = (uint32_t)DG_RL(v, __ffsll((long long)m) - 1);
@@ -1363,6 +1299,82 @@ __global__ __launch_bounds__(64) void k_cuts2(DgParams p) {
             if (found) { if (lane == 0) s_cut[nseg] = found; nseg++; }
         }
         __syncthreads();
+        // shared out-lists: enter's, and those of the vertices the prologue has visited whose out-edges
+        // lead into more than one segment; shared in-list: exit's
+        DgNode *ndw = p.nodes + p.node_base[t];
+        uint32_t *pool = p.pool + p.pool_base[t];
+        const uint32_t NT = p.n_nodes[t];
+        const int32_t *q0 = p.queue0 + p.node_base[t];
+        const uint32_t nvis = p.pro_state[4u * t + 2u];
+        uint32_t *tab = p.sh_cnt + (uint64_t)t * (2u + 2u * DG_SH_MAX);
+        __shared__ uint32_t s_sh[DG_SH_MAX];
+        __shared__ uint32_t s_nsh;
+        for (int attempt = 0; attempt < 2; attempt++) {
+            if (lane == 0) { s_sh[0] = 0u; s_nsh = 1u; }
+            __syncthreads();
+            if (nseg > 1)
+                for (uint32_t i0 = 1; i0 < nvis; i0 += 64) {
+                    const uint32_t i = i0 + (uint32_t)lane;
+                    bool multi = false;
+                    int y = 0;
+                    if (i < nvis) {
+                        y = q0[i];
+                        const DgNode ny = ndw[y];
+                        if (!(ny.flags & DG_NF_DELETED) && y != (int)NT - 1) {
+                            uint32_t sa = 0xFFFFFFFFu;
+                            for (uint32_t e = 0; e < ny.out_len; e++) {
+                                const uint32_t d = pool[ny.out_off + 2u * e];
+                                if (d == NT - 1u) continue;
+                                uint32_t sg = 0;                     // segment of d: cuts at or below it
+                                for (uint32_t c = 1; c < nseg; c++) sg += s_cut[c] <= d;
+                                if (sa == 0xFFFFFFFFu) sa = sg; else multi |= sg != sa;
+                            }
+                        }
+                    }
+                    const unsigned long long m = __ballot(multi);
+                    if (multi) {
+                        const uint32_t k = s_nsh + (uint32_t)__popcll(m & DG_LT(lane));
+                        if (k < DG_SH_MAX) s_sh[k] = (uint32_t)y;
+                    }
+                    __syncthreads();
+                    if (lane == 0) s_nsh += (uint32_t)__popcll(m);
+                    __syncthreads();
+                }
+            if (s_nsh <= DG_SH_MAX) break;
+            nseg = 1;                                        // too many shared lists: one piece (exact, slower)
+            __syncthreads();
+        }
+        const uint32_t nsh = s_nsh;
+        if (lane == 0) tab[0] = nsh;
+        // every shared list moves to where each segment has p.sh_log slots of its own behind the entries
+        // (tombstones to begin with): [entries][slots of segment 0][slots of segment 1] ...
+        for (uint32_t li = 0; li <= nsh; li++) {
+            const bool is_in = li == nsh;                    // the last one: in[exit]
+            const int v = is_in ? (int)NT - 1 : (int)s_sh[li];
+            const DgNode nv = ndw[v];
+            const uint32_t len = is_in ? nv.in_len : nv.out_len;
+            const uint32_t cap = len + nseg * p.sh_log;
+            const uint32_t words = is_in ? cap : 2u * cap;
+            uint32_t off = 0;
+            if (lane == 0) {
+                off = cap > 65535u ? 0xFFFFFFFFu : atomicAdd(&p.pool_top[t], words);
+                if (off == 0xFFFFFFFFu || (uint64_t)off + words > p.pool_size[t]) { dg_fail(p, DG_E_POOL_TGT); p.st->bad_target = t; off = 0xFFFFFFFFu; }
+            }
+            off = (uint32_t)DG_RL(off, 0);
+            if (off == 0xFFFFFFFFu) break;
+            const uint32_t old = is_in ? nv.in_off : nv.out_off;
+            const uint32_t lw = is_in ? len : 2u * len;
+            for (uint32_t i = lane; i < words; i += 64) {
+                uint32_t w = i < lw ? pool[old + i] : DG_TOMB;
+                if (!is_in && i >= lw && (i & 1u)) w = 0u;         // (count word of an empty slot)
+                pool[off + i] = w;
+            }
+            if (lane == 0) {
+                if (is_in) { ndw[v].in_off = off; ndw[v].in_cap = (uint16_t)cap; tab[1] = len; }
+                else { ndw[v].out_off = off; ndw[v].out_cap = (uint16_t)cap; tab[2u + 2u * li] = (uint32_t)v; tab[3u + 2u * li] = len; }
+                ndw[v].flags |= DG_NF_SHARED;
+            }
+        }
     }
     // the target's segments, in a row and in order
     __shared__ uint32_t s_base;
@@ -1392,24 +1404,30 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     DgNode *nd = p.nodes + nb;
     uint32_t *pool = p.pool + p.pool_base[t];
     const uint32_t NT = p.n_nodes[t];
-    for (int which = 0; which < 2; which++) {
-        const int v = which == 0 ? 0 : (int)NT - 1;
-        const uint32_t off = which == 0 ? nd[v].out_off : nd[v].in_off;
-        const uint32_t n = p.sh_cnt[2u * t + (uint32_t)which];
+    const uint32_t *tab = p.sh_cnt + (uint64_t)t * (2u + 2u * DG_SH_MAX);
+    const uint32_t nsh = tab[0] <= DG_SH_MAX ? tab[0] : DG_SH_MAX;
+    for (uint32_t li = 0; li <= nsh; li++) {
+        const bool is_in = li == nsh;
+        const int v = is_in ? (int)NT - 1 : (int)tab[2u + 2u * li];
+        const uint32_t off = is_in ? nd[v].in_off : nd[v].out_off;
+        const uint32_t n = is_in ? nd[v].in_cap : nd[v].out_cap;             // entries + every segment's slots
         uint32_t w = 0;                                    // entries kept so far
         for (uint32_t i0 = 0; i0 < n; i0 += 64) {
             const uint32_t i = i0 + (uint32_t)lane;
             uint32_t a = DG_TOMB, b = 0;
-            if (i < n) { a = which == 0 ? pool[off + 2u * i] : pool[off + i]; if (which == 0) b = pool[off + 2u * i + 1u]; }
+            if (i < n) { a = is_in ? pool[off + i] : pool[off + 2u * i]; if (!is_in) b = pool[off + 2u * i + 1u]; }
             const bool keep = a != DG_TOMB;
             const unsigned long long m = __ballot(keep);
             DG_WAVE_FENCE();                               // (all loads of the round before its stores: w <= i0)
             const uint32_t k = w + (uint32_t)__popcll(m & DG_LT(lane));
-            if (keep) { if (which == 0) { pool[off + 2u * k] = a; pool[off + 2u * k + 1u] = b; } else pool[off + k] = a; }
+            if (keep) { if (is_in) pool[off + k] = a; else { pool[off + 2u * k] = a; pool[off + 2u * k + 1u] = b; } }
             w += (uint32_t)__popcll(m);
             DG_WAVE_FENCE();
         }
-        if (lane == 0) { if (which == 0) nd[v].out_len = (uint16_t)w; else nd[v].in_len = (uint16_t)w; }
+        if (lane == 0) {
+            if (is_in) nd[v].in_len = (uint16_t)w; else nd[v].out_len = (uint16_t)w;
+            nd[v].flags &= (uint8_t)~DG_NF_SHARED;
+        }
     }
     DG_WAVE_FENCE();
     if (p.pro_state[4u * t + 3u] & 1u) return;            // (a tiny target: the prologue came as far as exit)

@@ -43,7 +43,10 @@ for rnd in range(rounds):
             if shift is None: os.environ.pop("DAGCON_EMIT_SHIFT", None)
             else: os.environ["DAGCON_EMIT_SHIFT"] = shift
             ctx = capi.Context(min_cov=min_cov, min_len=min_len, trim=trim, **kw)
-            got = ctx.consensus(b)
+            try:
+                got = ctx.consensus(b)
+            except capi.DagconError as e:
+                got = str(e)
             ctx.close()
             if got != exp:
                 bad += 1
