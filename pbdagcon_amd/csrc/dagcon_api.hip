@@ -71,6 +71,7 @@ struct Ctx {
     uint64_t norm_cap = 0, node_cap = 0, pool_cap = 0, cns_cap = 0, seg_cap = 0;
     uint32_t stk_words = 4096, growth_pct = 100, seg_max = 8, bp_max = 16, seg_env = 0;    // (scratch per target and segment: grown x4 and re-run on DG_E_STACK)
     uint32_t sh_log = 16;                           // slots per segment behind enter's / exit's list (x2 on DG_E_LOG_OVF)
+    bool full_span = false;                         // (nearly) every alignment of the batch covers its whole target
     uint32_t gcuts = 1;                             // partial-span cuts: prologue + worklist + epilogue (DAGCON_GCUTS=0: off)
     uint32_t tile_pos = 0, tile_words = 0, tile_ny = 0, tile_list_cap = 0, list_grid = 8192;   // LDS tiles (tile_pos 0: off)
     double ins_per_pos = -1.0;                      // inserted vertices per backbone position, from the last run
@@ -425,7 +426,7 @@ int dagcon_upload(dagcon_ctx *ctx, const dagcon_batch *b) {
     c->h_aln_len.clear(); c->h_aln_start.clear(); c->h_aln_tgt.clear(); c->h_aln_off.clear();
     c->max_k = 0; c->max_tlen = 0; c->sum_len = 0; c->sum_bb = 0; c->mat_cells = 0;
     c->have_bb = b->backbone != nullptr;
-    uint64_t bb_bytes = 0, n_full = 0;
+    uint64_t bb_bytes = 0, n_whole = 0;
     const uint64_t min_cov = c->opts.min_cov;
     for (uint32_t t = 0; t < T; t++) {
         const uint64_t ab = b->aln_begin[t], ae = b->aln_begin[t + 1];
@@ -447,7 +448,7 @@ int dagcon_upload(dagcon_ctx *ctx, const dagcon_batch *b) {
             c->h_aln_off.push_back(b->aln_off[a]);
             c->h_aln_tgt.push_back(t);
             c->sum_len += len;
-            n_full += (uint64_t)len * 10 >= (uint64_t)b->tlen[t] * 9;    // the strings cover (nearly) the whole target
+            n_whole += len >= b->tlen[t];                                  // (a read that spans the target has a column per target base)
         }
         const uint64_t k = c->h_aln_len.size() - c->h_aln_begin[t];
         if (k > DAGCON_MAX_COVERAGE)
@@ -469,6 +470,10 @@ int dagcon_upload(dagcon_ctx *ctx, const dagcon_batch *b) {
             bb_bytes = std::max<uint64_t>(bb_bytes, b->backbone_off[t] + b->tlen[t]);
         }
     }
+    // cuts for partial-span pileups (prologue + worklist + epilogue): where the reads are full-span the cut
+    // vertices every read passes through are the same ones, found without that machinery
+    c->full_span = n_whole == (uint64_t)c->h_aln_len.size();
+    c->gcuts = c->full_span ? 0u : 1u;
     if (const char *e = getenv("DAGCON_GCUTS")) c->gcuts = atoi(e) ? 1u : 0u;
     if (c->gcuts) c->tile_list_cap = std::max<uint32_t>(c->tile_list_cap, (uint32_t)std::min<uint64_t>((uint64_t)T * c->seg_max + 64, 0x0FFFFFFFull));
     // LDS tiles for mergeNodes: positions per tile from the LDS budget and the expected size of a
@@ -499,7 +504,7 @@ int dagcon_upload(dagcon_ctx *ctx, const dagcon_batch *b) {
     c->blob_bytes = b->blob_bytes;
     // cut vertices need every read to span them: with full-span reads a target is swept in seg_max
     // pieces, with partial spans in a few
-    c->expected_workers = n_full * 10 >= (uint64_t)c->A * 9 ? (uint64_t)T * c->seg_max : (uint64_t)T * 3;
+    c->expected_workers = c->full_span ? (uint64_t)T * c->seg_max : (uint64_t)T * 3;
     // windows of DG_NCH input columns: the units of the chunked normalizeGaps
     c->h_ch_base.assign((size_t)c->A + 1, 0);
     c->h_ch_aln.clear();

@@ -835,7 +835,8 @@ __global__ __launch_bounds__(64) void k_cuts(DgParams p) {
 #define DG_MM_WORKER 0
 #define DG_MM_PROLOGUE 1
 #define DG_MM_FINISH 2
-template <bool PF>
+// GC: compiled for p.gcuts (the full-span path, k_merge, carries none of the checks for shared lists)
+template <bool PF, bool GC = false>
 __device__ __forceinline__ void dg_merge_segment(const DgParams &p, const uint32_t t, const int c_start, const int c_end,
                                                  int32_t *stk_base, const int mode = DG_MM_WORKER, const uint32_t me = 0,
                                                  const uint32_t wlo = 0, const int lvl_stop = 0) {
@@ -854,12 +855,12 @@ __device__ __forceinline__ void dg_merge_segment(const DgParams &p, const uint32
         return;
     }
     DgGraph g;
-    const bool own_q = p.gcuts && c_start == 0 && mode != DG_MM_FINISH;     // (see DgParams::queue0)
+    const bool own_q = GC && p.gcuts && c_start == 0 && mode != DG_MM_FINISH;     // (see DgParams::queue0)
     g.nd = p.nodes + nb; g.queue = own_q ? p.queue0 + nb : p.queue + nb + c_start;          // the segment's own stretch of the queue
     g.pool = p.pool + p.pool_base[t]; g.pool_size = p.pool_size[t]; g.pool_top = p.pool_top + t;
     g.stk = stk_base; g.stk_words = p.stk_words;
     g.st = p.st; g.tfail = p.tfail + t; g.t = t; g.err = false;
-    const bool sh = p.gcuts && mode == DG_MM_WORKER;
+    const bool sh = GC && p.gcuts && mode == DG_MM_WORKER;
     g.sh = sh ? 1 : 0; g.X = (int)NT - 1;
     g.sh_tab = p.sh_cnt + (uint64_t)t * (2u + 2u * DG_SH_MAX); g.seg = me - wlo;
     g.lg_cap = p.sh_log; g.lg_cnt = p.seg_done + (uint64_t)me * (DG_SH_MAX + 1u);
@@ -1197,8 +1198,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
         const int c_start = (int)p.tile_list[5 + 3 * i];
         const uint32_t ce = p.tile_list[6 + 3 * i];
         if (dg_tskip(p, t)) continue;
-        dg_merge_segment<false>(p, t, c_start, ce == DG_NOSEG_END ? 0x7fffffff : (int)ce, p.stk + (uint64_t)blockIdx.x * p.stk_words,
-                                DG_MM_WORKER, i, p.gcuts ? p.wl_first[t] : 0u);
+        dg_merge_segment<false, true>(p, t, c_start, ce == DG_NOSEG_END ? 0x7fffffff : (int)ce, p.stk + (uint64_t)blockIdx.x * p.stk_words,
+                                      DG_MM_WORKER, i, p.gcuts ? p.wl_first[t] : 0u);
         if (threadIdx.x == 0) atomicAdd(&p.st->n_mseg, 1u);
         DG_WAVE_FENCE();
     }
@@ -1236,7 +1237,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     for (int o = 32; o; o >>= 1) { const uint32_t x = __shfl_xor(maxlead, o); maxlead = x > maxlead ? x : maxlead; }
     if (lane == 0) p.pro_state[4u * t + 3u] = 0u;
     DG_WAVE_FENCE();
-    dg_merge_segment<false>(p, t, 0, 0x7fffffff, p.stk + (uint64_t)blockIdx.x * p.stk_words, DG_MM_PROLOGUE, 0, 0, (int)maxlead + 1);
+    dg_merge_segment<false, true>(p, t, 0, 0x7fffffff, p.stk + (uint64_t)blockIdx.x * p.stk_words, DG_MM_PROLOGUE, 0, 0, (int)maxlead + 1);
 }
 
 // cuts for k_merge_list: up to p.seg_max pieces per target, conditions (1) - (4) above
@@ -1431,6 +1432,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     }
     DG_WAVE_FENCE();
     if (p.pro_state[4u * t + 3u] & 1u) return;            // (a tiny target: the prologue came as far as exit)
-    dg_merge_segment<false>(p, t, (int)NT - 1, 0x7fffffff, p.stk + (uint64_t)blockIdx.x * p.stk_words, DG_MM_FINISH);
+    dg_merge_segment<false, true>(p, t, (int)NT - 1, 0x7fffffff, p.stk + (uint64_t)blockIdx.x * p.stk_words, DG_MM_FINISH);
 }
 
