@@ -44,6 +44,7 @@ struct Opts {
     bool align = false, verbose = false, dump = false;
     std::vector<int> devices{0};       // --devices: one consensus worker (thread + context) per GPU
     int pinned = -1;                   // --pinned 0|1: page-locked blobs (-1: when the input is several batches long)
+    unsigned polish = 0;               // --polish N (with -a): N more rounds with the consensus as the new backbone
     size_t batch_targets = 256;        // small enough that parsing and the GPU overlap on mid-size inputs
     size_t batch_bytes = 1ull << 30;
     size_t slab_bytes = 0;             // test hook: text indexed per round (0 = automatic)
@@ -61,6 +62,9 @@ void usage(FILE *f) {
             "  -t, --trim          trim alignments on either side (default 50)\n"
             "  -a, --align         input is .pre (qid tid strand tlen tstart tend qseq tseq): align the sequences first\n"
             "  -v, --verbose       per-target progress on stderr\n"
+            "  --polish N          with -a: N more rounds, each with the previous round's consensus as the backbone the reads\n"
+            "                      are re-aligned to (README.md:14-15 of the reference: 'the new consensus can be used as a new\n"
+            "                      backbone sequence to iteratively improve the consensus quality')\n"
             "  --devices LIST      GPUs to use, e.g. 0,1,2,3 (default 0): one consensus worker per GPU, batches of\n"
             "                      targets dealt round-robin, records still printed in input order\n"
             "  <input>             BLASR -m 5 file (.pre with -a) sorted by target, or - for stdin\n"
@@ -93,6 +97,7 @@ int parse_args(int argc, char **argv, Opts &o) {
         else if (a == "--dump-parsed") o.dump = true;            // test hook: parser only, no GPU
         else if (a == "--slab-bytes") { unsigned v = 0; if (!need(&v)) return 2; o.slab_bytes = v; }   // test hook
         else if (a == "--batch-targets") { unsigned v = 0; if (!need(&v) || !v) return 2; o.batch_targets = v; }
+        else if (a == "--polish") { if (!need(&o.polish)) return 2; }
         else if (a == "--pinned") { unsigned v = 0; if (!need(&v)) return 2; o.pinned = v ? 1 : 0; }
         else if (a == "--devices") {
             if (i + 1 >= argc) { fprintf(stderr, "PARSE ERROR: --devices needs a list such as 0,1,2\n"); return 2; }
@@ -228,6 +233,106 @@ int flush(dagcon_ctx *ctx, Batch &b, const Opts &o) {
     if (rc != DAGCON_OK) {
         fprintf(stderr, "pbdagcon: consensus failed (%d): %s\n", rc, dagcon_last_error(ctx));
         return 1;
+    }
+    // --polish: the consensus becomes the backbone, the reads are aligned to it again, N times.  The
+    // reference names this use (README.md:14-15) and leaves it to the caller; nothing of it is in its
+    // C++ sources, so there is no reference behaviour to match: the steps are this build's own
+    // (longest segment as the new backbone, dagcon_align of every read against the stretch of it the
+    // read covered before, unaligned target flanks stripped, real-backbone consensus as dazcon.cpp:76).
+    std::vector<std::string> pol_bb;
+    std::vector<uint32_t> cur_start, cur_tb;               // per record: where its last alignment lay (0 target bases: dropped)
+    if (o.align && o.polish) {
+        const size_t A0 = b.start.size();
+        cur_start.assign(A0, 0); cur_tb.assign(A0, 0);
+        for (size_t a = 0; a < A0; a++) {
+            cur_start[a] = db.aln_start[a];
+            for (uint32_t i = 0; i < db.aln_len[a]; i++) cur_tb[a] += db.tstr[db.aln_off[a] + i] != '-';
+        }
+    }
+    std::vector<uint64_t> p_qoff, p_toff, p_ooff, p_begin, p_bboff;
+    std::vector<uint32_t> p_qlen, p_tlen, p_alen, p_start, p_tl;
+    std::string p_q, p_t, p_qa, p_ta, p_bb;
+    for (unsigned round = 1; o.align && round <= o.polish; round++) {
+        const uint32_t T = db.n_targets;
+        // new backbones: the longest segment (the first of the longest ones, as AlnGraphBoost.cpp:309,319 breaks ties)
+        std::vector<std::string> bb(T);
+        std::vector<int32_t> r0(T, 0);
+        for (uint32_t g = 0; g < T; g++) {
+            uint32_t best = 0;
+            for (uint64_t sg = r.seg_begin[g]; sg < r.seg_begin[g + 1]; sg++)
+                if (r.seq_len[sg] > best) { best = r.seq_len[sg]; bb[g].assign(r.seq_blob + r.seq_off[sg], r.seq_len[sg]); r0[g] = r.range0[sg]; }
+        }
+        // pairs: every read (in the target's orientation) against the stretch of the new backbone it covered
+        const size_t A = b.start.size();
+        p_qoff.assign(A, 0); p_toff.assign(A, 0); p_ooff.assign(A, 0); p_qlen.assign(A, 0); p_tlen.assign(A, 0);
+        p_alen.assign(A, 0); p_start.assign(A, 0);
+        std::vector<uint32_t> w0(A, 0);
+        p_q.clear(); p_t.clear();
+        uint64_t tot = 0;
+        size_t g = 0;
+        for (size_t a = 0; a < A; a++) {
+            while (b.begin[g + 1] <= a) g++;
+            const std::string &B = bb[g];
+            p_qoff[a] = p_q.size(); p_toff[a] = p_t.size(); p_ooff[a] = tot;
+            if (B.empty() || cur_tb[a] == 0) { cur_tb[a] = 0; continue; }   // (the target gave no consensus: its reads stay out)
+            // where the read lay on the previous backbone (1-based start, target bases of its alignment)
+            const uint32_t ps = cur_start[a], tb = cur_tb[a];
+            const uint32_t shift = o.trim + (uint32_t)r0[g];       // about where on it the consensus began
+            const uint32_t pad = 64u + tb / 10u;
+            const int64_t lo = (int64_t)ps - 1 - (int64_t)shift - (int64_t)pad, hi = (int64_t)ps - 1 + tb - (int64_t)shift + (int64_t)pad;
+            const uint32_t a0 = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(lo, (int64_t)B.size()));
+            const uint32_t a1 = (uint32_t)std::max<int64_t>(a0, std::min<int64_t>(hi, (int64_t)B.size()));
+            w0[a] = a0;
+            p_tlen[a] = a1 - a0;
+            p_t.append(B, a0, a1 - a0);
+            p_qlen[a] = b.len[a];
+            p_q.resize(p_q.size() + b.len[a]);
+            if (b.strand[a] == '-') revcomp_into(&p_q[p_qoff[a]], b.q.data() + b.off[a], b.len[a]);
+            else memcpy(&p_q[p_qoff[a]], b.q.data() + b.off[a], b.len[a]);
+            tot += (uint64_t)p_qlen[a] + p_tlen[a];
+        }
+        p_qa.assign(tot + 1, 0); p_ta.assign(tot + 1, 0);
+        if (p_q.empty()) p_q.push_back(0);
+        if (p_t.empty()) p_t.push_back(0);
+        rc = dagcon_align(ctx, (uint32_t)A, p_qoff.data(), p_qlen.data(), p_toff.data(), p_tlen.data(), p_q.data(), p_q.size(),
+                          p_t.data(), p_t.size(), p_ooff.data(), &p_qa[0], &p_ta[0], p_alen.data());
+        if (rc != DAGCON_OK) { fprintf(stderr, "pbdagcon: alignment failed (%d): %s\n", rc, dagcon_last_error(ctx)); return 1; }
+        // the alignment is global over the stretch: backbone bases in front of / behind the read are not part of it
+        for (size_t a = 0; a < A; a++) {
+            uint32_t n = p_alen[a], lead = 0;
+            uint64_t off = p_ooff[a];
+            while (n && p_qa[off] == '-') { off++; n--; lead++; }
+            while (n && p_qa[off + n - 1] == '-') n--;
+            p_ooff[a] = off; p_alen[a] = n; p_start[a] = w0[a] + lead + 1u;
+            if (cur_tb[a]) {
+                cur_start[a] = p_start[a];
+                uint32_t tb = 0;
+                for (uint32_t i = 0; i < n; i++) tb += p_ta[off + i] != '-';
+                cur_tb[a] = tb;
+            }
+        }
+        p_tl.assign(T, 0); p_bboff.assign(T, 0); p_bb.clear();
+        for (uint32_t t2 = 0; t2 < T; t2++) { p_tl[t2] = (uint32_t)bb[t2].size(); p_bboff[t2] = p_bb.size(); p_bb += bb[t2]; }
+        if (p_bb.empty()) p_bb.push_back('N');
+        // reads of a target without a backbone: none (their group then falls below -c)
+        p_begin.assign(b.begin.begin(), b.begin.end());
+        std::vector<uint32_t> k_start; std::vector<uint64_t> k_off; std::vector<uint32_t> k_len;
+        p_begin[0] = 0;
+        g = 0;
+        for (uint32_t t2 = 0; t2 < T; t2++) {
+            for (uint64_t a = b.begin[t2]; a < b.begin[t2 + 1]; a++)
+                if (cur_tb[a]) { k_start.push_back(p_start[a]); k_off.push_back(p_ooff[a]); k_len.push_back(p_alen[a]); }
+            p_begin[t2 + 1] = k_start.size();
+        }
+        p_start.swap(k_start); p_ooff.swap(k_off); p_alen.swap(k_len);
+        memset(&db, 0, sizeof db);
+        db.n_targets = T; db.tlen = p_tl.data(); db.aln_begin = p_begin.data();
+        db.aln_start = p_start.data(); db.aln_off = p_ooff.data(); db.aln_len = p_alen.data();
+        db.qstr = p_qa.data(); db.tstr = p_ta.data(); db.blob_bytes = tot;
+        db.backbone = p_bb.data(); db.backbone_off = p_bboff.data();
+        pol_bb.swap(bb);
+        rc = dagcon_consensus(ctx, &db, &r);
+        if (rc != DAGCON_OK) { fprintf(stderr, "pbdagcon: consensus failed (%d): %s\n", rc, dagcon_last_error(ctx)); return 1; }
     }
     char head[64];
     for (uint32_t g = 0; g < r.n_targets; g++) {

@@ -793,3 +793,97 @@ def test_cli_pre_input_with_align(tmp_path):
     out = subprocess.run([cli, "-a", "-j", "2", str(path)], capture_output=True, timeout=300)
     assert out.returncode == 0, out.stderr.decode()
     assert out.stdout == b"".join(exp) and len(exp) == 3
+
+
+def test_cli_polish_rounds(tmp_path):
+    """pbdagcon -a --polish N (the reference names the use in README.md:14-15 and has no code
+    for it): every round takes the longest consensus segment as the new backbone and aligns the reads to it
+    again.  The command line against the same steps composed on the CPU (twin aligner + oracle), byte for
+    byte; and the point of it: the consensus gets closer to the sequence the reads were drawn from."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cli = os.path.join(root, "pbdagcon_amd", "bin", "pbdagcon")
+    rng = np.random.default_rng(21)
+    rc = bytes.maketrans(b"ACGT", b"TGCA")
+    trim, min_cov, min_len = 50, 6, 500
+
+    def edit_distance(a, b):
+        prev = list(range(len(b) + 1))
+        for i, ca in enumerate(a, 1):
+            cur = [i]
+            for j, cb in enumerate(b, 1):
+                cur.append(min(prev[j] + 1, cur[-1] + 1, prev[j - 1] + (ca != cb)))
+            prev = cur
+        return prev[-1]
+
+    lines, targets = [], []
+    for ti in range(3):
+        truth = bytes(b"ACGT"[j] for j in rng.integers(0, 4, int(rng.integers(1400, 2000))))
+        backbone = _mutate(rng, truth, sub=0.04, ins=0.06, dele=0.06)        # the seed read: as noisy as the others
+        tlen = len(backbone)
+        recs = []
+        for r in range(12):
+            s = 0 if r % 3 else int(rng.integers(0, tlen // 5))
+            e = tlen if r % 3 else int(rng.integers(4 * tlen // 5, tlen + 1))
+            # the read is a noisy copy of the TRUTH over about the same stretch (mapped through the backbone's indels roughly)
+            ts, te = int(s * len(truth) / tlen), int(e * len(truth) / tlen)
+            strand = b"+-"[r % 2:r % 2 + 1]
+            q_fwd = _mutate(rng, truth[ts:te], sub=0.03, ins=0.07, dele=0.05)
+            tseq_fwd = backbone[s:e]
+            qseq = q_fwd if strand == b"+" else q_fwd.translate(rc)[::-1]
+            tseq = tseq_fwd if strand == b"+" else tseq_fwd.translate(rc)[::-1]
+            tstart = s if strand == b"+" else tlen - e
+            lines.append(b" ".join([b"q%d_%d" % (ti, r), b"t%d" % ti, strand, b"%d" % tlen, b"%d" % tstart,
+                                    b"%d" % (tstart + len(tseq)), qseq, tseq]))
+            recs.append((tstart, strand, qseq, tseq, q_fwd))
+        targets.append((truth, tlen, recs))
+    path = tmp_path / "in.pre"
+    path.write_bytes(b"\n".join(lines) + b"\n")
+
+    def twin(rounds):
+        out, cons = [], []
+        for ti, (truth, tlen, recs) in enumerate(targets):
+            alns, cur = [], []
+            for tstart, strand, qseq, tseq, q_fwd in recs:
+                st, en, qa, ta = oracle.simple_align(tstart, tlen, strand, qseq, tseq)
+                alns.append((st, qa, ta)); cur.append([st, len(ta) - ta.count(b"-")])
+            segs = oracle.consensus_target(tlen, alns, min_len, trim, min_cov) if len(alns) >= min_cov else []
+            for _ in range(rounds):
+                bb, r0 = b"", 0
+                for a0, a1, sq in segs:
+                    if len(sq) > len(bb):
+                        bb, r0 = sq, a0
+                alns = []
+                for k, (tstart, strand, qseq, tseq, q_fwd) in enumerate(recs):
+                    if not bb or cur[k][1] == 0:
+                        cur[k][1] = 0
+                        continue
+                    ps, tb = cur[k]
+                    shift, pad = trim + r0, 64 + tb // 10
+                    w0 = max(0, min(ps - 1 - shift - pad, len(bb)))
+                    w1 = max(w0, min(ps - 1 + tb - shift + pad, len(bb)))
+                    qa, ta = oracle.banded_align(q_fwd, bb[w0:w1])
+                    lead = len(qa) - len(qa.lstrip(b"-"))
+                    n = len(qa.rstrip(b"-"))
+                    qa, ta = qa[lead:n], ta[lead:n]
+                    cur[k] = [w0 + lead + 1, len(ta) - ta.count(b"-")]
+                    if cur[k][1]:
+                        alns.append((cur[k][0], qa, ta))
+                segs = oracle.consensus_target(len(bb), alns, min_len, trim, min_cov, backbone=bb) if (bb and len(alns) >= min_cov) else []
+            for a0, a1, sq in segs:
+                out.append(b">t%d/%d_%d\n%s\n" % (ti, a0, a1, sq))
+            cons.append(max((sq for _, _, sq in segs), key=len, default=b""))
+        return b"".join(out), cons
+
+    dist = {}
+    for rounds in (0, 1, 3):
+        got = subprocess.run([cli, "-a", "--polish", str(rounds), str(path)], capture_output=True, timeout=600)
+        assert got.returncode == 0, got.stderr.decode()
+        exp, cons = twin(rounds)
+        assert got.stdout == exp, f"--polish {rounds}"
+        assert all(cons), f"--polish {rounds}: a target lost its consensus"
+        # distance to the stretch of the truth the consensus covers (ends are trimmed off every round)
+        dist[rounds] = sum(min(edit_distance(c, t[o:o + len(c) + d]) for o in range(0, 400, 25) for d in (-20, 0, 20))
+                           for c, (t, _, _) in zip(cons, targets))
+    assert dist[3] < dist[0], dist
