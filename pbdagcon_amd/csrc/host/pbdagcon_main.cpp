@@ -239,100 +239,99 @@ int flush(dagcon_ctx *ctx, Batch &b, const Opts &o) {
     // C++ sources, so there is no reference behaviour to match: the steps are this build's own
     // (longest segment as the new backbone, dagcon_align of every read against the stretch of it the
     // read covered before, unaligned target flanks stripped, real-backbone consensus as dazcon.cpp:76).
-    std::vector<std::string> pol_bb;
-    std::vector<uint32_t> cur_start, cur_tb;               // per record: where its last alignment lay (0 target bases: dropped)
+    // Every round: (1) the longest segment is the new backbone; it covers about positions
+    // [trim + range0, trim + range1) of the previous one.  (2) From its previous alignment each read is
+    // clipped to what lies over that stretch (plus a margin) and the stretch of the new backbone it covers is
+    // estimated; (3) dagcon_align, global over the two pieces, backbone bases in front of / behind the read
+    // stripped; (4) real-backbone consensus as dazcon.cpp:76 does.
     if (o.align && o.polish) {
-        const size_t A0 = b.start.size();
-        cur_start.assign(A0, 0); cur_tb.assign(A0, 0);
-        for (size_t a = 0; a < A0; a++) {
-            cur_start[a] = db.aln_start[a];
-            for (uint32_t i = 0; i < db.aln_len[a]; i++) cur_tb[a] += db.tstr[db.aln_off[a] + i] != '-';
-        }
-    }
-    std::vector<uint64_t> p_qoff, p_toff, p_ooff, p_begin, p_bboff;
-    std::vector<uint32_t> p_qlen, p_tlen, p_alen, p_start, p_tl;
-    std::string p_q, p_t, p_qa, p_ta, p_bb;
-    for (unsigned round = 1; o.align && round <= o.polish; round++) {
-        const uint32_t T = db.n_targets;
-        // new backbones: the longest segment (the first of the longest ones, as AlnGraphBoost.cpp:309,319 breaks ties)
-        std::vector<std::string> bb(T);
-        std::vector<int32_t> r0(T, 0);
-        for (uint32_t g = 0; g < T; g++) {
-            uint32_t best = 0;
-            for (uint64_t sg = r.seg_begin[g]; sg < r.seg_begin[g + 1]; sg++)
-                if (r.seq_len[sg] > best) { best = r.seq_len[sg]; bb[g].assign(r.seq_blob + r.seq_off[sg], r.seq_len[sg]); r0[g] = r.range0[sg]; }
-        }
-        // pairs: every read (in the target's orientation) against the stretch of the new backbone it covered
         const size_t A = b.start.size();
-        p_qoff.assign(A, 0); p_toff.assign(A, 0); p_ooff.assign(A, 0); p_qlen.assign(A, 0); p_tlen.assign(A, 0);
-        p_alen.assign(A, 0); p_start.assign(A, 0);
-        std::vector<uint32_t> w0(A, 0);
-        p_q.clear(); p_t.clear();
-        uint64_t tot = 0;
-        size_t g = 0;
-        for (size_t a = 0; a < A; a++) {
-            while (b.begin[g + 1] <= a) g++;
-            const std::string &B = bb[g];
-            p_qoff[a] = p_q.size(); p_toff[a] = p_t.size(); p_ooff[a] = tot;
-            if (B.empty() || cur_tb[a] == 0) { cur_tb[a] = 0; continue; }   // (the target gave no consensus: its reads stay out)
-            // where the read lay on the previous backbone (1-based start, target bases of its alignment)
-            const uint32_t ps = cur_start[a], tb = cur_tb[a];
-            const uint32_t shift = o.trim + (uint32_t)r0[g];       // about where on it the consensus began
-            const uint32_t pad = 64u + tb / 10u;
-            const int64_t lo = (int64_t)ps - 1 - (int64_t)shift - (int64_t)pad, hi = (int64_t)ps - 1 + tb - (int64_t)shift + (int64_t)pad;
-            const uint32_t a0 = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(lo, (int64_t)B.size()));
-            const uint32_t a1 = (uint32_t)std::max<int64_t>(a0, std::min<int64_t>(hi, (int64_t)B.size()));
-            w0[a] = a0;
-            p_tlen[a] = a1 - a0;
-            p_t.append(B, a0, a1 - a0);
-            p_qlen[a] = b.len[a];
-            p_q.resize(p_q.size() + b.len[a]);
-            if (b.strand[a] == '-') revcomp_into(&p_q[p_qoff[a]], b.q.data() + b.off[a], b.len[a]);
-            else memcpy(&p_q[p_qoff[a]], b.q.data() + b.off[a], b.len[a]);
-            tot += (uint64_t)p_qlen[a] + p_tlen[a];
-        }
-        p_qa.assign(tot + 1, 0); p_ta.assign(tot + 1, 0);
-        if (p_q.empty()) p_q.push_back(0);
-        if (p_t.empty()) p_t.push_back(0);
-        rc = dagcon_align(ctx, (uint32_t)A, p_qoff.data(), p_qlen.data(), p_toff.data(), p_tlen.data(), p_q.data(), p_q.size(),
-                          p_t.data(), p_t.size(), p_ooff.data(), &p_qa[0], &p_ta[0], p_alen.data());
-        if (rc != DAGCON_OK) { fprintf(stderr, "pbdagcon: alignment failed (%d): %s\n", rc, dagcon_last_error(ctx)); return 1; }
-        // the alignment is global over the stretch: backbone bases in front of / behind the read are not part of it
-        for (size_t a = 0; a < A; a++) {
-            uint32_t n = p_alen[a], lead = 0;
-            uint64_t off = p_ooff[a];
-            while (n && p_qa[off] == '-') { off++; n--; lead++; }
-            while (n && p_qa[off + n - 1] == '-') n--;
-            p_ooff[a] = off; p_alen[a] = n; p_start[a] = w0[a] + lead + 1u;
-            if (cur_tb[a]) {
-                cur_start[a] = p_start[a];
-                uint32_t tb = 0;
-                for (uint32_t i = 0; i < n; i++) tb += p_ta[off + i] != '-';
-                cur_tb[a] = tb;
+        const uint32_t T = db.n_targets;
+        const uint32_t pad = 64;
+        std::vector<uint32_t> cur_start(A), cur_len(A), cur_qbase(A, 0);   // qbase: the read's base the current alignment begins with
+        std::vector<uint64_t> cur_off(A);
+        std::string cur_q(qa), cur_t(ta);                  // the reads' last alignments, per record
+        for (size_t a = 0; a < A; a++) { cur_start[a] = db.aln_start[a]; cur_off[a] = db.aln_off[a]; cur_len[a] = db.aln_len[a]; }
+        std::vector<uint64_t> p_qoff(A), p_toff(A), p_ooff(A), p_begin, p_bboff;
+        std::vector<uint32_t> p_qlen(A), p_tlen(A), p_alen(A), p_tl, w0(A);
+        std::string p_q, p_t, p_qa, p_ta, p_bb, fwd;
+        std::vector<uint32_t> k_start, k_len; std::vector<uint64_t> k_off;
+        for (unsigned round = 1; round <= o.polish; round++) {
+            std::vector<std::string> bb(T);
+            std::vector<int32_t> r0(T, 0), r1(T, 0);
+            for (uint32_t g = 0; g < T; g++) {
+                uint32_t best = 0;                           // (the first of the longest ones, as AlnGraphBoost.cpp:309,319 breaks ties)
+                for (uint64_t sg = r.seg_begin[g]; sg < r.seg_begin[g + 1]; sg++)
+                    if (r.seq_len[sg] > best) { best = r.seq_len[sg]; bb[g].assign(r.seq_blob + r.seq_off[sg], r.seq_len[sg]); r0[g] = r.range0[sg]; r1[g] = r.range1[sg]; }
             }
+            p_q.clear(); p_t.clear();
+            uint64_t tot = 0;
+            size_t g = 0;
+            for (size_t a = 0; a < A; a++) {
+                while (b.begin[g + 1] <= a) g++;
+                const std::string &B = bb[g];
+                p_qoff[a] = p_q.size(); p_toff[a] = p_t.size(); p_ooff[a] = tot; p_qlen[a] = 0; p_tlen[a] = 0; w0[a] = 0;
+                if (B.empty() || cur_len[a] == 0) { cur_len[a] = 0; continue; }     // (no consensus, or nothing left of the read)
+                // the new backbone lies over [lo_t, hi_t) of the previous one, margins included (0-based)
+                const int64_t org = (int64_t)o.trim + r0[g];
+                const int64_t lo_t = org - pad, hi_t = (int64_t)o.trim + r1[g] + pad;
+                int64_t tpos = (int64_t)cur_start[a] - 1;
+                uint32_t qpos = 0, qlo = 0, qhi = 0;
+                int64_t t_first = -1, t_last = -1;
+                for (uint32_t i = 0; i < cur_len[a]; i++) {
+                    const char qc = cur_q[cur_off[a] + i], tc = cur_t[cur_off[a] + i];
+                    const bool in = tpos >= lo_t && tpos < hi_t;
+                    if (qc != '-') { if (tpos < lo_t) qlo = qpos + 1; if (in) qhi = qpos + 1; qpos++; }
+                    if (in && tc != '-') { if (t_first < 0) t_first = tpos; t_last = tpos; }
+                    if (tc != '-') tpos++;
+                }
+                if (qhi <= qlo || t_first < 0) { cur_len[a] = 0; continue; }
+                const int64_t a0 = std::max<int64_t>(0, std::min<int64_t>(t_first - org - pad, (int64_t)B.size()));
+                const int64_t a1 = std::max<int64_t>(a0, std::min<int64_t>(t_last + 1 - org + pad, (int64_t)B.size()));
+                w0[a] = (uint32_t)a0; p_tlen[a] = (uint32_t)(a1 - a0);
+                p_t.append(B, (size_t)a0, (size_t)(a1 - a0));
+                // the read in the target's orientation, clipped
+                fwd.resize(b.len[a]);
+                if (b.strand[a] == '-') revcomp_into(&fwd[0], b.q.data() + b.off[a], b.len[a]);
+                else memcpy(&fwd[0], b.q.data() + b.off[a], b.len[a]);
+                p_qlen[a] = qhi - qlo;
+                p_q.append(fwd, cur_qbase[a] + qlo, qhi - qlo);
+                cur_qbase[a] += qlo;
+                tot += (uint64_t)p_qlen[a] + p_tlen[a];
+            }
+            p_qa.assign(tot + 1, 0); p_ta.assign(tot + 1, 0);
+            if (p_q.empty()) p_q.push_back(0);
+            if (p_t.empty()) p_t.push_back(0);
+            rc = dagcon_align(ctx, (uint32_t)A, p_qoff.data(), p_qlen.data(), p_toff.data(), p_tlen.data(), p_q.data(), p_q.size(),
+                              p_t.data(), p_t.size(), p_ooff.data(), &p_qa[0], &p_ta[0], p_alen.data());
+            if (rc != DAGCON_OK) { fprintf(stderr, "pbdagcon: alignment failed (%d): %s\n", rc, dagcon_last_error(ctx)); return 1; }
+            // global over the two pieces: backbone bases in front of / behind the read are not part of its alignment
+            k_start.clear(); k_off.clear(); k_len.clear();
+            p_begin.assign(1, 0);
+            g = 0;
+            for (size_t a = 0; a < A; a++) {
+                while (b.begin[g + 1] <= a) { g++; p_begin.push_back(k_start.size()); }
+                if (cur_len[a] == 0) continue;
+                uint32_t n = p_alen[a], lead = 0;
+                uint64_t off = p_ooff[a];
+                while (n && p_qa[off] == '-') { off++; n--; lead++; }
+                while (n && p_qa[off + n - 1] == '-') n--;
+                cur_start[a] = w0[a] + lead + 1u; cur_off[a] = off; cur_len[a] = n;
+                if (n) { k_start.push_back(cur_start[a]); k_off.push_back(off); k_len.push_back(n); }
+            }
+            while (p_begin.size() < (size_t)T + 1) p_begin.push_back(k_start.size());
+            cur_q.swap(p_qa); cur_t.swap(p_ta);            // (the next round clips against these)
+            p_tl.assign(T, 0); p_bboff.assign(T, 0); p_bb.clear();
+            for (uint32_t t2 = 0; t2 < T; t2++) { p_tl[t2] = (uint32_t)bb[t2].size(); p_bboff[t2] = p_bb.size(); p_bb += bb[t2]; }
+            if (p_bb.empty()) p_bb.push_back('N');
+            memset(&db, 0, sizeof db);
+            db.n_targets = T; db.tlen = p_tl.data(); db.aln_begin = p_begin.data();
+            db.aln_start = k_start.data(); db.aln_off = k_off.data(); db.aln_len = k_len.data();
+            db.qstr = cur_q.data(); db.tstr = cur_t.data(); db.blob_bytes = cur_q.size();
+            db.backbone = p_bb.data(); db.backbone_off = p_bboff.data();
+            rc = dagcon_consensus(ctx, &db, &r);
+            if (rc != DAGCON_OK) { fprintf(stderr, "pbdagcon: consensus failed (%d): %s\n", rc, dagcon_last_error(ctx)); return 1; }
         }
-        p_tl.assign(T, 0); p_bboff.assign(T, 0); p_bb.clear();
-        for (uint32_t t2 = 0; t2 < T; t2++) { p_tl[t2] = (uint32_t)bb[t2].size(); p_bboff[t2] = p_bb.size(); p_bb += bb[t2]; }
-        if (p_bb.empty()) p_bb.push_back('N');
-        // reads of a target without a backbone: none (their group then falls below -c)
-        p_begin.assign(b.begin.begin(), b.begin.end());
-        std::vector<uint32_t> k_start; std::vector<uint64_t> k_off; std::vector<uint32_t> k_len;
-        p_begin[0] = 0;
-        g = 0;
-        for (uint32_t t2 = 0; t2 < T; t2++) {
-            for (uint64_t a = b.begin[t2]; a < b.begin[t2 + 1]; a++)
-                if (cur_tb[a]) { k_start.push_back(p_start[a]); k_off.push_back(p_ooff[a]); k_len.push_back(p_alen[a]); }
-            p_begin[t2 + 1] = k_start.size();
-        }
-        p_start.swap(k_start); p_ooff.swap(k_off); p_alen.swap(k_len);
-        memset(&db, 0, sizeof db);
-        db.n_targets = T; db.tlen = p_tl.data(); db.aln_begin = p_begin.data();
-        db.aln_start = p_start.data(); db.aln_off = p_ooff.data(); db.aln_len = p_alen.data();
-        db.qstr = p_qa.data(); db.tstr = p_ta.data(); db.blob_bytes = tot;
-        db.backbone = p_bb.data(); db.backbone_off = p_bboff.data();
-        pol_bb.swap(bb);
-        rc = dagcon_consensus(ctx, &db, &r);
-        if (rc != DAGCON_OK) { fprintf(stderr, "pbdagcon: consensus failed (%d): %s\n", rc, dagcon_last_error(ctx)); return 1; }
     }
     char head[64];
     for (uint32_t g = 0; g < r.n_targets; g++) {

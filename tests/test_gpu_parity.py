@@ -795,6 +795,58 @@ def test_cli_pre_input_with_align(tmp_path):
     assert out.stdout == b"".join(exp) and len(exp) == 3
 
 
+def _polish_twin(tlen, recs, rounds, trim, min_cov, min_len, pad=64):
+    """The steps of `pbdagcon -a --polish N` (csrc/host/pbdagcon_main.cpp) composed on the CPU:
+    recs = [(tstart, strand, qseq, tseq, q_fwd)] of one target -> segments after `rounds` rounds."""
+    alns, cur = [], []
+    for tstart, strand, qseq, tseq, q_fwd in recs:
+        st, en, qa, ta = oracle.simple_align(tstart, tlen, strand, qseq, tseq)
+        alns.append((st, qa, ta)); cur.append([st, qa, ta, 0])
+    segs = oracle.consensus_target(tlen, alns, min_len, trim, min_cov) if len(alns) >= min_cov else []
+    for _ in range(rounds):
+        bb, r0, r1 = b"", 0, 0
+        for a0, a1, sq in segs:
+            if len(sq) > len(bb):
+                bb, r0, r1 = sq, a0, a1
+        alns = []
+        for k, (tstart, strand, qseq, tseq, q_fwd) in enumerate(recs):
+            st, qa, ta, qb = cur[k]
+            if not bb or not qa:
+                cur[k] = [0, b"", b"", 0]
+                continue
+            org = trim + r0
+            lo_t, hi_t = org - pad, trim + r1 + pad
+            tpos, qpos, qlo, qhi, t_first, t_last = st - 1, 0, 0, 0, -1, -1
+            for qc, tc in zip(qa, ta):
+                inside = lo_t <= tpos < hi_t
+                if qc != 0x2D:
+                    if tpos < lo_t:
+                        qlo = qpos + 1
+                    if inside:
+                        qhi = qpos + 1
+                    qpos += 1
+                if inside and tc != 0x2D:
+                    if t_first < 0:
+                        t_first = tpos
+                    t_last = tpos
+                if tc != 0x2D:
+                    tpos += 1
+            if qhi <= qlo or t_first < 0:
+                cur[k] = [0, b"", b"", 0]
+                continue
+            w0 = max(0, min(t_first - org - pad, len(bb)))
+            w1 = max(w0, min(t_last + 1 - org + pad, len(bb)))
+            qa2, ta2 = oracle.banded_align(q_fwd[qb + qlo:qb + qhi], bb[w0:w1])
+            lead = len(qa2) - len(qa2.lstrip(b"-"))
+            n = len(qa2.rstrip(b"-"))
+            qa2, ta2 = qa2[lead:n], ta2[lead:n]
+            cur[k] = [w0 + lead + 1, qa2, ta2, qb + qlo]
+            if qa2:
+                alns.append((w0 + lead + 1, qa2, ta2))
+        segs = oracle.consensus_target(len(bb), alns, min_len, trim, min_cov, backbone=bb) if (bb and len(alns) >= min_cov) else []
+    return segs
+
+
 def test_cli_polish_rounds(tmp_path):
     """pbdagcon -a --polish N (the reference names the use in README.md:14-15 and has no code
     for it): every round takes the longest consensus segment as the new backbone and aligns the reads to it
@@ -806,28 +858,32 @@ def test_cli_polish_rounds(tmp_path):
     cli = os.path.join(root, "pbdagcon_amd", "bin", "pbdagcon")
     rng = np.random.default_rng(21)
     rc = bytes.maketrans(b"ACGT", b"TGCA")
-    trim, min_cov, min_len = 50, 6, 500
+    trim, min_cov, min_len = 20, 6, 500
 
-    def edit_distance(a, b):
-        prev = list(range(len(b) + 1))
-        for i, ca in enumerate(a, 1):
-            cur = [i]
-            for j, cb in enumerate(b, 1):
-                cur.append(min(prev[j] + 1, cur[-1] + 1, prev[j - 1] + (ca != cb)))
+    def infix_distance(c, t):
+        """edit distance of c to the best-matching stretch of t"""
+        prev = np.zeros(len(t) + 1, dtype=np.int64)
+        tt = np.frombuffer(t, np.uint8)
+        for ch in c:
+            sub = prev[:-1] + (tt != ch)
+            cur = np.empty_like(prev)
+            cur[0] = prev[0] + 1
+            np.minimum(sub, prev[1:] + 1, out=cur[1:])
+            # (insertions along the row: a running minimum of cur[j-1] + 1)
+            cur = np.minimum.accumulate(cur - np.arange(cur.size)) + np.arange(cur.size)
             prev = cur
-        return prev[-1]
+        return int(prev.min())
 
     lines, targets = [], []
     for ti in range(3):
-        truth = bytes(b"ACGT"[j] for j in rng.integers(0, 4, int(rng.integers(1400, 2000))))
+        truth = bytes(b"ACGT"[j] for j in rng.integers(0, 4, int(rng.integers(1500, 2000))))
         backbone = _mutate(rng, truth, sub=0.04, ins=0.06, dele=0.06)        # the seed read: as noisy as the others
         tlen = len(backbone)
         recs = []
-        for r in range(12):
+        for r in range(24):
             s = 0 if r % 3 else int(rng.integers(0, tlen // 5))
             e = tlen if r % 3 else int(rng.integers(4 * tlen // 5, tlen + 1))
-            # the read is a noisy copy of the TRUTH over about the same stretch (mapped through the backbone's indels roughly)
-            ts, te = int(s * len(truth) / tlen), int(e * len(truth) / tlen)
+            ts, te = int(s * len(truth) / tlen), int(e * len(truth) / tlen)   # about the same stretch of the truth
             strand = b"+-"[r % 2:r % 2 + 1]
             q_fwd = _mutate(rng, truth[ts:te], sub=0.03, ins=0.07, dele=0.05)
             tseq_fwd = backbone[s:e]
@@ -840,50 +896,17 @@ def test_cli_polish_rounds(tmp_path):
         targets.append((truth, tlen, recs))
     path = tmp_path / "in.pre"
     path.write_bytes(b"\n".join(lines) + b"\n")
-
-    def twin(rounds):
-        out, cons = [], []
-        for ti, (truth, tlen, recs) in enumerate(targets):
-            alns, cur = [], []
-            for tstart, strand, qseq, tseq, q_fwd in recs:
-                st, en, qa, ta = oracle.simple_align(tstart, tlen, strand, qseq, tseq)
-                alns.append((st, qa, ta)); cur.append([st, len(ta) - ta.count(b"-")])
-            segs = oracle.consensus_target(tlen, alns, min_len, trim, min_cov) if len(alns) >= min_cov else []
-            for _ in range(rounds):
-                bb, r0 = b"", 0
-                for a0, a1, sq in segs:
-                    if len(sq) > len(bb):
-                        bb, r0 = sq, a0
-                alns = []
-                for k, (tstart, strand, qseq, tseq, q_fwd) in enumerate(recs):
-                    if not bb or cur[k][1] == 0:
-                        cur[k][1] = 0
-                        continue
-                    ps, tb = cur[k]
-                    shift, pad = trim + r0, 64 + tb // 10
-                    w0 = max(0, min(ps - 1 - shift - pad, len(bb)))
-                    w1 = max(w0, min(ps - 1 + tb - shift + pad, len(bb)))
-                    qa, ta = oracle.banded_align(q_fwd, bb[w0:w1])
-                    lead = len(qa) - len(qa.lstrip(b"-"))
-                    n = len(qa.rstrip(b"-"))
-                    qa, ta = qa[lead:n], ta[lead:n]
-                    cur[k] = [w0 + lead + 1, len(ta) - ta.count(b"-")]
-                    if cur[k][1]:
-                        alns.append((cur[k][0], qa, ta))
-                segs = oracle.consensus_target(len(bb), alns, min_len, trim, min_cov, backbone=bb) if (bb and len(alns) >= min_cov) else []
-            for a0, a1, sq in segs:
-                out.append(b">t%d/%d_%d\n%s\n" % (ti, a0, a1, sq))
-            cons.append(max((sq for _, _, sq in segs), key=len, default=b""))
-        return b"".join(out), cons
-
-    dist = {}
-    for rounds in (0, 1, 3):
-        got = subprocess.run([cli, "-a", "--polish", str(rounds), str(path)], capture_output=True, timeout=600)
+    err = {}
+    for rounds in (0, 1, 2):
+        got = subprocess.run([cli, "-a", "-t", str(trim), "--polish", str(rounds), str(path)], capture_output=True, timeout=600)
         assert got.returncode == 0, got.stderr.decode()
-        exp, cons = twin(rounds)
-        assert got.stdout == exp, f"--polish {rounds}"
-        assert all(cons), f"--polish {rounds}: a target lost its consensus"
-        # distance to the stretch of the truth the consensus covers (ends are trimmed off every round)
-        dist[rounds] = sum(min(edit_distance(c, t[o:o + len(c) + d]) for o in range(0, 400, 25) for d in (-20, 0, 20))
-                           for c, (t, _, _) in zip(cons, targets))
-    assert dist[3] < dist[0], dist
+        exp, e = [], 0.0
+        for ti, (truth, tlen, recs) in enumerate(targets):
+            segs = _polish_twin(tlen, recs, rounds, trim, min_cov, min_len)
+            assert segs, f"--polish {rounds}: target {ti} lost its consensus"
+            exp += [b">t%d/%d_%d\n%s\n" % (ti, a0, a1, sq) for a0, a1, sq in segs]
+            best = max((sq for _, _, sq in segs), key=len)
+            e += infix_distance(best, truth) / len(best)
+        assert got.stdout == b"".join(exp), f"--polish {rounds}"
+        err[rounds] = e
+    assert err[2] < err[0] and err[1] < err[0], err
