@@ -64,7 +64,7 @@ struct Ctx {
     DevBuf d_node_base, d_n_nodes, d_pool_base, d_pool_size, d_pool_top, d_t_nins;
     DevBuf d_matA, d_matD, d_matC, d_cov, d_gcount, d_gbase, d_bid;
     DevBuf d_nodes, d_best, d_queue, d_score, d_cns_tmp, d_bp_tt;
-    DevBuf d_pool, d_stk, d_cuts, d_cuts_bp, d_bp_stat, d_bp_len, d_nextcut, d_tile_list, d_rd, d_pro_state, d_sh_cnt, d_seg_done, d_wl_first, d_queue0;
+    DevBuf d_pool, d_stk, d_cuts, d_cuts_bp, d_bp_stat, d_bp_len, d_nextcut, d_tile_list, d_rd, d_pro_state, d_sh_cnt, d_seg_done, d_wl_first, d_queue0, d_bp_end, d_bp_ab, d_defer, d_cns_tmp0;
     DevBuf d_al[12];                                // dagcon_align: blobs, offsets, outputs, directions
     DevBuf d_cns, d_cns_off, d_cns_len, d_seg_first, d_n_seg, d_seg_r0, d_seg_r1, d_st;
 
@@ -163,6 +163,10 @@ int ensure_arenas(Ctx *c) {
         ENSURE(c, c->d_seg_done, (uint64_t)c->tile_list_cap * (DG_SH_MAX + 1) * 4 + 16);
         ENSURE(c, c->d_wl_first, (uint64_t)c->T * 4 + 16);
         ENSURE(c, c->d_queue0, c->node_cap * 4);
+        ENSURE(c, c->d_bp_end, (uint64_t)c->T * c->bp_max * 4 + 16);
+        ENSURE(c, c->d_bp_ab, (uint64_t)c->T * c->bp_max * 16 + 16);
+        ENSURE(c, c->d_defer, (uint64_t)c->T * (DG_DEFER_MAX + 1) * 4 + 16);
+        ENSURE(c, c->d_cns_tmp0, c->node_cap);
     }
     ENSURE(c, c->d_cuts, (uint64_t)c->T * (c->seg_max + 2) * 4);
     ENSURE(c, c->d_cuts_bp, (uint64_t)c->T * (c->bp_max + 2) * 4);
@@ -226,7 +230,8 @@ void fill_params(Ctx *c, DgParams &p) {
     p.gcuts = c->gcuts; p.sh_log = c->sh_log;
     p.rd_s = (uint32_t *)c->d_rd.p; p.rd_e = p.rd_s + c->A; p.rd_lead = p.rd_e + c->A; p.rd_trail = p.rd_lead + c->A;
     p.pro_state = (uint32_t *)c->d_pro_state.p; p.sh_cnt = (uint32_t *)c->d_sh_cnt.p;
-    p.queue0 = (int32_t *)c->d_queue0.p;
+    p.queue0 = (int32_t *)c->d_queue0.p; p.bp_end = (uint32_t *)c->d_bp_end.p; p.bp_ab = (float *)c->d_bp_ab.p;
+    p.defer = (uint32_t *)c->d_defer.p; p.cns_tmp0 = (uint8_t *)c->d_cns_tmp0.p;
     p.seg_done = (uint32_t *)c->d_seg_done.p; p.wl_first = (uint32_t *)c->d_wl_first.p;
     p.nextcut = (uint32_t *)c->d_nextcut.p; p.tile_pos = c->tile_pos; p.tile_words = c->tile_words;
     p.tile_list = (uint32_t *)c->d_tile_list.p; p.tile_list_cap = c->tile_list_cap;
@@ -302,9 +307,20 @@ int launch_all(Ctx *c) {
     HIPCHK(c, hipEventRecord(c->ev[3], s));
     if (c->T > 0 && !(c->opts.flags & (DAGCON_FLAG_STOP_AFTER_BUILD | DAGCON_FLAG_STOP_AFTER_MERGE))) {
         hipLaunchKernelGGL(k_bp_terms, dim3(c->T, 16), dim3(256), 0, s, p);
-        hipLaunchKernelGGL(k_bp_sweep, dim3(c->T * c->bp_max), dim3(64), 0, s, p);
-        hipLaunchKernelGGL(k_bp_check, dim3(c->T), dim3(64), 0, s, p);
-        hipLaunchKernelGGL(k_bp_walk, dim3(c->T * c->bp_max), dim3(64), 0, s, p);
+        if (c->gcuts && !c->tile_pos) {
+            // partial-span pileups: the pieces of k_cuts2, three sweeps (A, B, absolute), see dg_bp_sweep
+            hipLaunchKernelGGL(k_bp_sweep_g<0>, dim3(c->T * c->bp_max), dim3(64), 0, s, p);
+            hipLaunchKernelGGL(k_bp_reset_def, dim3(c->T), dim3(64), 0, s, p);
+            hipLaunchKernelGGL(k_bp_sweep_g<1>, dim3(c->T * c->bp_max), dim3(64), 0, s, p);
+            hipLaunchKernelGGL(k_bp_comb, dim3(c->T), dim3(64), 0, s, p);
+            hipLaunchKernelGGL(k_bp_sweep_g<2>, dim3(c->T * c->bp_max), dim3(64), 0, s, p);
+            hipLaunchKernelGGL(k_bp_defer, dim3(c->T), dim3(64), 0, s, p);
+            hipLaunchKernelGGL(k_bp_walk_g, dim3(c->T * c->bp_max), dim3(64), 0, s, p);
+        } else {
+            hipLaunchKernelGGL(k_bp_sweep, dim3(c->T * c->bp_max), dim3(64), 0, s, p);
+            hipLaunchKernelGGL(k_bp_check, dim3(c->T), dim3(64), 0, s, p);
+            hipLaunchKernelGGL(k_bp_walk, dim3(c->T * c->bp_max), dim3(64), 0, s, p);
+        }
         hipLaunchKernelGGL(k_bp_join, dim3(c->T), dim3(64), 0, s, p);
     }
     HIPCHK(c, hipEventRecord(c->ev[4], s));
@@ -376,7 +392,7 @@ void dagcon_destroy(dagcon_ctx *ctx) {
                      &c->d_n_ins, &c->d_n_del, &c->d_norm, &c->d_node_base, &c->d_n_nodes,
                      &c->d_pool_base, &c->d_pool_size, &c->d_pool_top, &c->d_t_nins, &c->d_matA, &c->d_matD,
                      &c->d_matC, &c->d_cov, &c->d_gcount, &c->d_gbase, &c->d_bid, &c->d_nodes,
-                     &c->d_best, &c->d_queue, &c->d_score, &c->d_cns_tmp, &c->d_bp_tt, &c->d_pool, &c->d_stk, &c->d_cuts, &c->d_cuts_bp, &c->d_bp_stat, &c->d_bp_len, &c->d_nextcut, &c->d_tile_list, &c->d_rd, &c->d_pro_state, &c->d_sh_cnt, &c->d_seg_done, &c->d_wl_first, &c->d_queue0, &c->d_cns,
+                     &c->d_best, &c->d_queue, &c->d_score, &c->d_cns_tmp, &c->d_bp_tt, &c->d_pool, &c->d_stk, &c->d_cuts, &c->d_cuts_bp, &c->d_bp_stat, &c->d_bp_len, &c->d_nextcut, &c->d_tile_list, &c->d_rd, &c->d_pro_state, &c->d_sh_cnt, &c->d_seg_done, &c->d_wl_first, &c->d_queue0, &c->d_bp_end, &c->d_bp_ab, &c->d_defer, &c->d_cns_tmp0, &c->d_cns,
                      &c->d_cns_off, &c->d_cns_len, &c->d_seg_first, &c->d_n_seg, &c->d_seg_r0, &c->d_seg_r1,
                      &c->d_st};
     for (DevBuf *b : all) free_buf(*b);

@@ -74,6 +74,7 @@ struct __attribute__((aligned(16))) DgNode {
 };
 #define DG_NF_BACKBONE 1u
 #define DG_NF_DELETED  2u
+#define DG_NF_DEFER    8u   // bestPath on partial-span pileups: scored by k_bp_defer, after the segments' sweeps
 #define DG_NF_SHARED   4u   // during k_merge_list: a list of this vertex is shared by the segments' workers (DgGraph::sh)
 
 // arrival cell: (target base << 25) | (source id + 1); deletion: id field all ones
@@ -83,6 +84,7 @@ struct __attribute__((aligned(16))) DgNode {
 #define DG_MAX_NODES    0x1FFFFFDu
 #define DG_EMIT_SEG     512u   // backbone positions per k_emit wave: default of DgParams::emit_shift (1 << 9)
 #define DG_CK_NONE      0xFFFFFFFFu
+#define DG_DEFER_MAX    64u
 #define DG_SH_MAX       8u            // shared out-lists per target (enter + vertices of the prologue that reach into several segments)
 #define DG_TOMB         0xFFFFFFFFu   // erased entry of a shared list (enter's out-list, exit's in-list)
 
@@ -166,6 +168,10 @@ struct DgParams {
     uint32_t *cuts_bp;             //   its waves are light), [T][bp_max + 2] like cuts
     float *bp_stat;                // [T][seg_max][2]: largest |score| of the segment, score of its first vertex
     uint32_t *bp_len;              // [T][seg_max]: vertices of the best path inside the segment (enter / exit excluded)
+    uint32_t *bp_end;              // [T][bp_max] (p.gcuts): where a piece of the walk ended (k_bp_walk)
+    float *bp_ab;                  // [T][bp_max][4] (p.gcuts): A, B of the segment's first vertex, absolute score of its upper cut
+    uint32_t *defer;               // [T][DG_DEFER_MAX + 1] (p.gcuts): count, then the vertices k_bp_defer scores
+    uint8_t *cns_tmp0;             // (p.gcuts) the walk's first piece, from enter to the first cut it meets
     // ---- cuts for partial-span pileups (k_readspan, k_merge_pro, k_cuts2, k_merge_list, k_merge_fin) ----
     uint32_t gcuts;                // 1: mergeNodes runs as prologue + worklist of segments + epilogue
     uint32_t *rd_s, *rd_e;         // [A] first / last backbone position a read consumes (0 / 0: the read is empty)

@@ -99,13 +99,28 @@ struct DgWalkShared {
 // vertex every path of this stretch ends in (the next cut, see k_cuts); it counts as
 // score 0 and is not evaluated, so the scores are relative to it.  amax = largest
 // |score| seen.
+// Partial-span pileups (p.gcuts): a segment between two cuts of k_cuts2 may hold vertices with an edge
+// to the exit vertex (reads end there), so a path can leave it without passing its upper cut.  The
+// recurrence is linear in (max, +): with A[x] = best x -> upper cut and B[x] = best x -> exit past it,
+// score[x] = max(A[x] + score[cut], B[x]).  The same sweep gives A with (cut, exit) worth (0, -inf), B with
+// (-inf, 0) and the absolute scores with (score[cut], 0): ctv / xv are those two values, xid the exit
+// vertex (-1: it is a vertex of the stretch itself).  skip_def: the stream passes over the vertices flagged
+// DG_NF_DEFER -- enter, and the few vertices the merge's prologue visited whose successors lie in another
+// segment than their own id (chains reads begin with, united at enter), with their ancestors.  One of
+// them whose successors all lie in ONE segment is scored when a vertex of that segment asks for it (the
+// evaluation stack); what nobody asks for is scored by k_bp_defer, after the sweeps.
+#define DG_BP_NINF (-1.0e9f)
+#define DG_BP_ONE 0xFFFFFFFFu      // DgParams::defer[0]: the target is swept in one piece; bp_end of the first piece: it ended at exit
 __device__ __forceinline__ void dg_bp_sweep(DgBpShared &S, const DgNode *nd, int32_t *best, float2 *score,
                                             const uint32_t *pool, const float *tt, const int v_top, const int v_bot,
                                             const int c_top, int32_t *gstk, const int gstk_cap,
-                                            const int lane, float &amax, bool &bad, bool &stuck) {
+                                            const int lane, float &amax, bool &bad, bool &stuck,
+                                            const float ctv = 0.0f, const int xid = -1, const float xv = 0.0f,
+                                            const bool skip_def = false) {
+    const int dead_mask = (int)DG_NF_DELETED | (skip_def ? (int)DG_NF_DEFER : 0);
     for (int i = lane; i < DG_SR; i += 64) S.stag[i] = -1;
     for (int i = lane; i < DG_BR; i += 64) S.tag[i] = -1;
-    if (c_top >= 0 && lane == 0) { S.stag[c_top & (DG_SR - 1)] = c_top; S.sval[c_top & (DG_SR - 1)] = 0.0f; }
+    if (c_top >= 0 && lane == 0) { S.stag[c_top & (DG_SR - 1)] = c_top; S.sval[c_top & (DG_SR - 1)] = ctv; }
 
     // ---- staging registers: r_* = records of a chunk, e_* = its edges ----
     uint4 r_lo, r_hi, n_lo, n_hi;
@@ -214,7 +229,7 @@ __device__ __forceinline__ void dg_bp_sweep(DgBpShared &S, const DgNode *nd, int
         {
             const int vl = v_hi - lane;
             const int lnl = vl >= v_lo ? S.lens[vl & (DG_BR - 1)] : (int)DG_BL_DONE;
-            live = __ballot(!(lnl & DG_BL_DONE) && !((lnl >> 16) & DG_NF_DELETED));
+            live = __ballot(!(lnl & DG_BL_DONE) && !((lnl >> 16) & dead_mask));
         }
         int pf_ln = 0, pf_d = 0;
         float pf_w = 0.0f;
@@ -263,7 +278,7 @@ __device__ __forceinline__ void dg_bp_sweep(DgBpShared &S, const DgNode *nd, int
                             S.rscore[xs] = mx; S.rbest[xs] = bd;
                             S.lens[xs] = ln | DG_BL_DONE;
                         }
-                        amax = fmaxf(amax, fabsf(mx));
+                        if (mx > 0.5f * DG_BP_NINF) amax = fmaxf(amax, fabsf(mx));
                         if (ndef) woken = collect(v, 0);          // (rare: somebody far above waits for v)
                         if (!woken) continue;
                     }
@@ -293,7 +308,7 @@ __device__ __forceinline__ void dg_bp_sweep(DgBpShared &S, const DgNode *nd, int
                     lens = __builtin_amdgcn_readfirstlane((int)DG_BL_HBM | (int)((lo.y >> 8) & 0xffu) << 16 |
                                                           (fin == 1.0f ? (int)DG_BL_DONE : 0));
                 }
-                if ((lens & DG_BL_DONE) || ((lens >> 16) & DG_NF_DELETED)) { sp--; continue; }
+                if ((lens & DG_BL_DONE) || ((lens >> 16) & DG_NF_DELETED)) { sp--; continue; }   // (a deferred vertex is scored when somebody asks for it)
                 int out_len = lens & 0xffff;
                 const bool hbm = (lens & DG_BL_HBM) != 0;
                 uint32_t out_off = 0;
@@ -327,7 +342,8 @@ __device__ __forceinline__ void dg_bp_sweep(DgBpShared &S, const DgNode *nd, int
                         // edge makes thousands finish early): a vertex of a resident chunk keeps its
                         // result in its slot until the chunk's row store, everything else is in HBM
                         const int yd = d & (DG_BR - 1);
-                        if (d == c_top) { have = true; sc = 0.0f; }       // the segment's reference point
+                        if (d == c_top) { have = true; sc = ctv; }        // the segment's reference point
+                        else if (d == xid) { have = true; sc = xv; }      // an edge to the exit vertex, which lies beyond the stretch
                         else if (S.tag[yd] == d && (S.lens[yd] & DG_BL_DONE) && d >= v_lo) { have = true; sc = S.rscore[yd]; }
                         else {
                             const float2 sg = score[d];
@@ -390,7 +406,7 @@ __device__ __forceinline__ void dg_bp_sweep(DgBpShared &S, const DgNode *nd, int
                 }
                 // (a vertex scored before its chunk is unpacked is scored again at its turn:
                 // same successors, same result)
-                amax = fmaxf(amax, fabsf(mx));
+                if (mx > 0.5f * DG_BP_NINF) amax = fmaxf(amax, fabsf(mx));
                 sp--;
                 if (ndef) {                                // those that waited for n are next
                     if (sp + 1 + ndef > DG_BSTK + gstk_cap) { bad = true; break; }
@@ -558,12 +574,25 @@ __global__ __launch_bounds__(64) void k_bp_join(DgParams p) {
     if (dg_failed(p) || dg_tskip(p, t)) return;
     const int lane = threadIdx.x;
     const uint64_t nb = p.node_base[t];
-    const uint32_t *crow = p.cuts_bp + (uint64_t)t * (p.bp_max + 2u);
+    const uint32_t *crow = p.gcuts ? p.cuts + (uint64_t)t * (p.seg_max + 2u) : p.cuts_bp + (uint64_t)t * (p.bp_max + 2u);
     const uint32_t nseg = crow[0];
     __shared__ uint32_t s_off[65], s_c0[64];
     {
         // where each segment's piece of the path goes (seg_max <= 64: one lane per segment)
-        const uint32_t len = (uint32_t)lane < nseg ? p.bp_len[(uint64_t)t * p.bp_max + lane] : 0u;
+        uint32_t len = (uint32_t)lane < nseg ? p.bp_len[(uint64_t)t * p.bp_max + lane] : 0u;
+        if (p.gcuts) {
+            // the pieces that are on the path: the one from enter, which ends at cut number a (or at exit), then
+            // a, a + 1, ... up to the first one that ends at exit instead of at the next cut
+            const uint32_t e = (uint32_t)lane < nseg ? p.bp_end[(uint64_t)t * p.bp_max + lane] : 1u;
+            const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)e, 0);
+            const unsigned long long ends = __ballot((uint32_t)lane >= 1u && (uint32_t)lane < nseg && e == 0u);
+            bool on = lane == 0;
+            if (a != DG_BP_ONE && a < 64u && (ends >> a)) {
+                const uint32_t fe = a + (uint32_t)__ffsll((long long)(ends >> a)) - 1u;
+                on |= (uint32_t)lane >= a && (uint32_t)lane <= fe;
+            }
+            if (!on) len = 0;
+        }
         uint32_t incl = len;
         for (int o = 1; o < 64; o <<= 1) { const uint32_t up = __shfl_up(incl, o); if (lane >= o) incl += up; }
         s_off[lane] = incl - len;
@@ -581,7 +610,7 @@ __global__ __launch_bounds__(64) void k_bp_join(DgParams p) {
     uint32_t offs = 0, nout = 0, keep = 0;
     for (uint32_t s = 0; s < nseg; s++) {
         const uint32_t len = s_off[s + 1 < 64 ? s + 1 : 64] - s_off[s], g0s = s_off[s];
-        const uint8_t *src = tmp + s_c0[s];
+        const uint8_t *src = (p.gcuts && s == 0) ? p.cns_tmp0 + nb : tmp + s_c0[s];
         for (uint32_t j0 = 0; j0 < len; j0 += 64) {
             const uint32_t n = len - j0 < 64 ? len - j0 : 64;
             const bool valid = (uint32_t)lane < n;
@@ -631,11 +660,231 @@ __global__ __launch_bounds__(64) void k_bp_join(DgParams p) {
     uint8_t *out = p.cns + co;
     for (uint32_t s = 0; s < nseg; s++) {
         const uint32_t g0s = s_off[s], len = s_off[s + 1 < 64 ? s + 1 : 64] - s_off[s];
-        const uint8_t *src = tmp + s_c0[s];
+        const uint8_t *src = (p.gcuts && s == 0) ? p.cns_tmp0 + nb : tmp + s_c0[s];
         for (uint32_t j = lane; j < len && g0s + j < keep; j += 64) out[g0s + j] = (uint8_t)(src[j] & 0x7fu);
     }
     for (uint32_t i = lane; i < nout; i += 64) {
         p.seg_r0[so + i] = segs[2 * i];
         p.seg_r1[so + i] = segs[2 * i + 1];
+    }
+}
+
+
+// ====================================================================================
+// bestPath on the pieces of k_cuts2 (partial-span pileups, p.gcuts): see dg_bp_sweep.
+//   k_bp_sweep_g<0>  A of every piece but the last (cut worth 0, exit -inf); the last piece, which ends
+//                    in the exit vertex, gets its absolute scores at once
+//   k_bp_sweep_g<1>  B of every piece but the last (cut -inf, exit 0)
+//   k_bp_comb        per target: the absolute score of every cut, from the last one down:
+//                    score[c_k] = max(A_k + score[c_k+1], B_k); the exactness bound; deferred vertices reset
+//   k_bp_sweep_g<2>  the absolute scores and first-maximum choices of every piece but the last
+//                    (a target that failed the bound, or has too many deferred vertices: one sweep, as a whole)
+//   k_bp_defer       the deferred vertices nobody asked for (enter is the last of them)
+//   k_bp_walk_g      the best-edge walk in pieces: from every cut to the next cut or to exit, and from
+//                    enter to the first cut it meets;  k_bp_join chains the pieces that are on the path
+// ====================================================================================
+
+__global__ __launch_bounds__(64) void k_bp_reset_def(DgParams p) {
+    const uint32_t t = blockIdx.x;
+    if (dg_failed(p) || dg_tskip(p, t)) return;
+    const uint32_t *dl = p.defer + (uint64_t)t * (DG_DEFER_MAX + 1u);
+    const uint32_t n = dl[0];
+    if (n == DG_BP_ONE) return;
+    const uint64_t nb = p.node_base[t];
+    for (uint32_t i = threadIdx.x; i < n; i += 64) { p.score[nb + dl[1 + i]] = make_float2(0.0f, 0.0f); p.best[nb + dl[1 + i]] = -1; }
+}
+
+template <int PASS>
+__global__ __launch_bounds__(64) void k_bp_sweep_g(DgParams p) {
+    const uint32_t t = blockIdx.x / p.bp_max, seg = blockIdx.x % p.bp_max;
+    if (dg_failed(p) || dg_tskip(p, t)) return;
+    const uint32_t *crow = p.cuts + (uint64_t)t * (p.seg_max + 2u);
+    const uint32_t nseg = crow[0];
+    if (seg >= nseg) return;
+    const int lane = threadIdx.x;
+    const uint64_t nb = p.node_base[t];
+    __shared__ DgBpShared S;
+    const int N = (int)p.n_nodes[t];
+    float2 *score = p.score + nb;
+    const bool one = p.defer[(uint64_t)t * (DG_DEFER_MAX + 1u)] == DG_BP_ONE || nseg <= 1;
+    float amax = 0.0f;
+    bool bad = false, stuck = false;
+    if (one) {
+        // in one piece, as the reference does it (every vertex in the stream, the deferred ones too)
+        if (PASS != 2 || seg != 0) return;
+        for (int i = lane; i < N; i += 64) score[i] = make_float2(0.0f, 0.0f);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        dg_bp_sweep(S, p.nodes + nb, p.best + nb, score, p.pool + p.pool_base[t], p.bp_tt + nb, N - 1, 0, -1,
+                    p.stk + (uint64_t)blockIdx.x * p.stk_words, (int)p.stk_words, lane, amax, bad, stuck);
+    } else {
+        const bool last = seg + 1 == nseg;
+        if (last && PASS != 0) return;
+        const int c_bot = (int)crow[1 + seg];
+        const int c_top = last ? -1 : (int)crow[2 + seg];
+        const int v_top = last ? N - 1 : c_top - 1;
+        if (PASS != 0) {
+            for (int i = c_bot + lane; i <= v_top; i += 64) score[i] = make_float2(0.0f, 0.0f);   // (the pass before left its own)
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        }
+        float *ab = p.bp_ab + 4ull * blockIdx.x;
+        const float ctv = PASS == 0 ? 0.0f : PASS == 1 ? DG_BP_NINF : ab[2];
+        const float xv = PASS == 0 ? DG_BP_NINF : 0.0f;
+        dg_bp_sweep(S, p.nodes + nb, p.best + nb, score, p.pool + p.pool_base[t], p.bp_tt + nb, v_top, c_bot, c_top,
+                    p.stk + (uint64_t)blockIdx.x * p.stk_words, (int)p.stk_words, lane, amax, bad, stuck,
+                    ctv, last ? -1 : N - 1, xv, true);
+        if (!bad) {
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            const float a = score[c_bot].x;                    // (piece 0 begins with enter, which is deferred: not used)
+            if (lane == 0) {
+                if (PASS == 0) { ab[0] = a; ab[3] = amax; }
+                else if (PASS == 1) { ab[1] = a; ab[3] = fmaxf(ab[3], amax); }
+                else ab[3] = fmaxf(ab[3], amax);
+            }
+        }
+    }
+    if (bad && lane == 0) { if (stuck) dg_fail_target(p, t, DG_E_INTERNAL); else { dg_fail(p, DG_E_STACK); p.st->bad_target = t; } }
+}
+
+__global__ __launch_bounds__(64) void k_bp_comb(DgParams p) {
+    const uint32_t t = blockIdx.x;
+    if (dg_failed(p) || dg_tskip(p, t)) return;
+    const uint32_t *crow = p.cuts + (uint64_t)t * (p.seg_max + 2u);
+    const int nseg = (int)crow[0];
+    uint32_t *dl = p.defer + (uint64_t)t * (DG_DEFER_MAX + 1u);
+    if (nseg <= 1 || dl[0] == DG_BP_ONE) return;
+    const uint64_t nb = p.node_base[t];
+    if (threadIdx.x == 0) {
+        // every score is a multiple of 0.5: fp32 is exact below 2^23.  What the pieces' relative and the
+        // reference's absolute arithmetic can form stays below 2^22 if every piece's largest value, the
+        // absolute score of its upper cut and one edge term do (k_bp_check has the argument); else one piece
+        bool redo = (p.flags & DG_F_RESWEEP) != 0;
+        const float K = (float)(uint32_t)(p.aln_begin[t + 1] - p.aln_begin[t]);
+        const float wmax = K > 10.0f ? K : 10.0f;
+        float *ab = p.bp_ab + 4ull * ((uint64_t)t * p.bp_max);
+        float abs_ = ab[4 * (nseg - 1)];                                   // the last piece's first vertex, absolute
+        if (!(ab[4 * (nseg - 1) + 3] + wmax < 4194304.0f)) redo = true;
+        for (int k = nseg - 2; k >= 0; k--) {
+            ab[4 * k + 2] = abs_;
+            if (!(ab[4 * k + 3] + fabsf(abs_) + wmax < 4194304.0f)) redo = true;
+            if (k >= 1) {
+                const float viaA = ab[4 * k] + abs_, viaB = ab[4 * k + 1];
+                abs_ = viaA > viaB ? viaA : viaB;
+            }
+        }
+        if (redo) dl[0] = DG_BP_ONE;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    const uint32_t n = dl[0];
+    if (n == DG_BP_ONE) return;
+    for (uint32_t i = threadIdx.x; i < n; i += 64) { p.score[nb + dl[1 + i]] = make_float2(0.0f, 0.0f); p.best[nb + dl[1 + i]] = -1; }
+}
+
+// the deferred vertices that no sweep was asked for: each once all its successors have their scores
+__global__ __launch_bounds__(64) void k_bp_defer(DgParams p) {
+    const uint32_t t = blockIdx.x;
+    if (dg_failed(p) || dg_tskip(p, t)) return;
+    const uint32_t *dl = p.defer + (uint64_t)t * (DG_DEFER_MAX + 1u);
+    const uint32_t n = dl[0];
+    if (n == DG_BP_ONE || threadIdx.x != 0) return;
+    const uint64_t nb = p.node_base[t];
+    const DgNode *nd = p.nodes + nb;
+    const uint32_t *pool = p.pool + p.pool_base[t];
+    const float *tt = p.bp_tt + nb;
+    float2 *score = p.score + nb;
+    int32_t *best = p.best + nb;
+    uint32_t left = n;
+    for (uint32_t round = 0; round <= n && left; round++) {
+        left = 0;
+        for (uint32_t i = 0; i < n; i++) {
+            const int v = (int)dl[1 + i];
+            if (score[v].y == 1.0f || (nd[v].flags & DG_NF_DELETED)) continue;
+            const DgNode nv = nd[v];
+            bool ready = true;
+            float mx = 0.0f;
+            int bd = -1;
+            for (uint32_t e = 0; e < nv.out_len; e++) {
+                const int d = (int)pool[nv.out_off + 2u * e];
+                const float2 sd = score[d];
+                if (sd.y != 1.0f) { ready = false; break; }
+                const float td = tt[d];
+                const float w = td == DG_TT_TEN ? -10.0f : (float)(int)pool[nv.out_off + 2u * e + 1u] - td;     // :404-408
+                const float ns = w + sd.x;
+                if (e == 0 || ns > mx) { mx = ns; bd = d; }                 // :399-416 first maximum, strict '>'
+            }
+            if (!ready) { left++; continue; }
+            score[v] = make_float2(mx, 1.0f);
+            best[v] = bd;
+        }
+    }
+    if (left) dg_fail_target(p, t, DG_E_INTERNAL);
+}
+
+__global__ __launch_bounds__(64) void k_bp_walk_g(DgParams p) {
+    const uint32_t t = blockIdx.x / p.bp_max, seg = blockIdx.x % p.bp_max;
+    if (dg_failed(p) || dg_tskip(p, t)) return;
+    const uint32_t *crow = p.cuts + (uint64_t)t * (p.seg_max + 2u);
+    const uint32_t nseg = crow[0];
+    if (seg >= nseg) return;
+    const int lane = threadIdx.x;
+    const uint64_t nb = p.node_base[t];
+    __shared__ DgWalkShared W;
+    const DgNode *nd = p.nodes + nb;
+    const int32_t *best = p.best + nb;
+    const int N = (int)p.n_nodes[t];
+    for (int i = lane; i < DG_WR; i += 64) W.wtag[i] = -1;
+    const int c0 = (int)crow[1 + seg];
+    const int c1 = seg + 1 < nseg ? (int)crow[2 + seg] : -1;
+    const int mycut = (uint32_t)lane >= 1u && (uint32_t)lane < nseg ? (int)crow[1 + lane] : -1;   // piece 0 stops at any cut
+    const uint8_t eb = nd[0].base, xb = nd[N - 1].base;
+    const int minw = p.min_weight;
+    uint8_t *tmp = seg == 0 ? p.cns_tmp0 + nb : p.cns_tmp + nb + c0;
+    int v = c0, cs = c0 >> 6, idx = 0;
+    uint32_t steps = 0, endk = 0;                          // endk: piece 0: cut index reached (DG_BP_ONE: exit); others: 1 = the next cut
+    bool bad = false;
+    if (seg == 0) endk = DG_BP_ONE;
+    for (;;) {
+        if (seg != 0) { if (v == c1) { endk = 1; break; } }
+        else if (v != c0) {
+            const unsigned long long hit = __ballot(mycut == v);
+            if (hit) { endk = (uint32_t)__ffsll((long long)hit) - 1u; break; }
+        }
+        if (v > 64 * cs + 512) cs = v >> 6;                  // (a jump: enter's edges lead anywhere)
+        while (64 * cs < N && 64 * cs < v + 192) {           // (best, base, weight) of 64 ids ahead
+            const int id = 64 * cs + lane;
+            if (id < N) {
+                const uint4 h = *reinterpret_cast<const uint4 *>(&nd[id]);
+                const int b = best[id];
+                const int xw = id & (DG_WR - 1);
+                W.wtag[xw] = id; W.wbest[xw] = b; W.wbase[xw] = (int)(h.y & 0xffu); W.wweight[xw] = (int)h.z;
+            }
+            cs++;
+        }
+        const int xw = v & (DG_WR - 1);
+        int nxt, w;
+        uint8_t base;
+        const int wt = W.wtag[xw], wb = W.wbest[xw], wa = W.wbase[xw], ww = W.wweight[xw];
+        if (__builtin_amdgcn_readfirstlane(wt) == v) {
+            nxt = __builtin_amdgcn_readfirstlane(wb); base = (uint8_t)__builtin_amdgcn_readfirstlane(wa);
+            w = __builtin_amdgcn_readfirstlane(ww);
+        } else {
+            const uint4 h = *reinterpret_cast<const uint4 *>(&nd[v]);
+            nxt = __builtin_amdgcn_readfirstlane(best[v]);
+            base = (uint8_t)__builtin_amdgcn_readfirstlane((int)(h.y & 0xffu));
+            w = __builtin_amdgcn_readfirstlane((int)h.z);
+        }
+        if (!(base == eb || base == xb)) {
+            if (lane == 0) W.wbuf[idx & 63] = (unsigned char)(base | (w >= minw ? 0x80u : 0u));
+            if ((idx & 63) == 63) tmp[(idx & ~63) + lane] = W.wbuf[lane];
+            idx++;
+        }
+        if (nxt < 0) break;
+        v = nxt;
+        if (++steps > (uint32_t)N) { bad = true; break; }
+    }
+    if (lane < (idx & 63)) tmp[(idx & ~63) + lane] = W.wbuf[lane];     // the last, partial row
+    if (lane == 0) {
+        if (bad) dg_fail_target(p, t, DG_E_INTERNAL);
+        p.bp_len[blockIdx.x] = (uint32_t)idx;
+        p.bp_end[blockIdx.x] = endk;
     }
 }

@@ -1377,6 +1377,12 @@ __global__ __launch_bounds__(64) void k_cuts2(DgParams p) {
             }
         }
     }
+    // (bestPath sweeps the same pieces: dg_bp_sweep)
+    {
+        uint32_t *crow = p.cuts + (uint64_t)t * (p.seg_max + 2u);
+        if (lane == 0) crow[0] = nseg;
+        for (uint32_t s2 = lane; s2 < nseg; s2 += 64) crow[1 + s2] = skip ? 0u : s_cut[s2];
+    }
     // the target's segments, in a row and in order
     __shared__ uint32_t s_base;
     if (lane == 0) {
@@ -1431,7 +1437,49 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
         }
     }
     DG_WAVE_FENCE();
-    if (p.pro_state[4u * t + 3u] & 1u) return;            // (a tiny target: the prologue came as far as exit)
-    dg_merge_segment<false, true>(p, t, (int)NT - 1, 0x7fffffff, p.stk + (uint64_t)blockIdx.x * p.stk_words, DG_MM_FINISH);
+    if (!(p.pro_state[4u * t + 3u] & 1u))                 // (a tiny target: the prologue came as far as exit)
+        dg_merge_segment<false, true>(p, t, (int)NT - 1, 0x7fffffff, p.stk + (uint64_t)blockIdx.x * p.stk_words, DG_MM_FINISH);
+    DG_WAVE_FENCE();
+    // what bestPath's segment sweeps must leave alone (DG_NF_DEFER, see dg_bp_sweep): enter, the vertices the
+    // prologue visited that have a successor in another segment than their own id, and their ancestors
+    {
+        const uint32_t *crow = p.cuts + (uint64_t)t * (p.seg_max + 2u);
+        const uint32_t nseg = crow[0];
+        const int32_t *q0 = p.queue0 + nb;
+        const uint32_t nvis = p.pro_state[4u * t + 2u];
+        uint32_t *dl = p.defer + (uint64_t)t * (DG_DEFER_MAX + 1u);
+        uint32_t nd_ = 0;
+        bool ovf = false;
+        if (lane == 0) {
+            nd[0].flags |= DG_NF_DEFER; dl[1] = 0u; nd_ = 1;
+            if (nseg > 1) {
+                for (bool more = true; more && !ovf;) {
+                    more = false;
+                    for (uint32_t i = 1; i < nvis && !ovf; i++) {
+                        const int y = q0[i];
+                        const DgNode ny = nd[y];
+                        if ((ny.flags & (DG_NF_DELETED | DG_NF_DEFER)) || y == (int)NT - 1) continue;
+                        uint32_t sy = 0;
+                        for (uint32_t c = 1; c < nseg; c++) sy += crow[1 + c] <= (uint32_t)y;
+                        bool f = false;
+                        for (uint32_t e = 0; e < ny.out_len && !f; e++) {
+                            const uint32_t d = pool[ny.out_off + 2u * e];
+                            if (d == NT - 1u) continue;
+                            if (nd[d].flags & DG_NF_DEFER) { f = true; break; }
+                            uint32_t sd = 0;
+                            for (uint32_t c = 1; c < nseg; c++) sd += crow[1 + c] <= d;
+                            f = sd != sy;
+                        }
+                        if (f) {
+                            if (nd_ >= DG_DEFER_MAX) { ovf = true; break; }
+                            nd[y].flags |= DG_NF_DEFER; dl[1 + nd_] = (uint32_t)y; nd_++;
+                            more = true;
+                        }
+                    }
+                }
+            }
+            dl[0] = ovf ? 0xFFFFFFFFu : nd_;                 // (too many: bestPath sweeps the target in one piece)
+        }
+    }
 }
 
