@@ -309,6 +309,7 @@ int launch_all(Ctx *c) {
         hipLaunchKernelGGL(k_bp_terms, dim3(c->T, 16), dim3(256), 0, s, p);
         if (c->gcuts && !c->tile_pos) {
             // partial-span pileups: the pieces of k_cuts2, three sweeps (A, B, absolute), see dg_bp_sweep
+            hipLaunchKernelGGL(k_bp_xtree, dim3(c->T), dim3(64), 0, s, p);
             hipLaunchKernelGGL(k_bp_sweep_g<0>, dim3(c->T * c->bp_max), dim3(64), 0, s, p);
             hipLaunchKernelGGL(k_bp_reset_def, dim3(c->T), dim3(64), 0, s, p);
             hipLaunchKernelGGL(k_bp_sweep_g<1>, dim3(c->T * c->bp_max), dim3(64), 0, s, p);

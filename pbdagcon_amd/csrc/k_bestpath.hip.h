@@ -109,6 +109,10 @@ struct DgWalkShared {
 // segment than their own id (chains reads begin with, united at enter), with their ancestors.  One of
 // them whose successors all lie in ONE segment is scored when a vertex of that segment asks for it (the
 // evaluation stack); what nobody asks for is scored by k_bp_defer, after the sweeps.
+// The other end: mergeInNodes(exit) unites the vertices reads END with (one out-edge, to exit, equal bases),
+// wherever on the backbone they lie, and its recursion their predecessors: edges from anywhere into that
+// little tree.  Its scores depend on nothing but exit, so k_bp_xtree has them first (final flag 2.0) and an
+// edge into it is an escape like an edge to exit itself: -inf for A, its absolute score for B and the rest.
 #define DG_BP_NINF (-1.0e9f)
 #define DG_BP_ONE 0xFFFFFFFFu      // DgParams::defer[0]: the target is swept in one piece; bp_end of the first piece: it ended at exit
 __device__ __forceinline__ void dg_bp_sweep(DgBpShared &S, const DgNode *nd, int32_t *best, float2 *score,
@@ -306,7 +310,7 @@ __device__ __forceinline__ void dg_bp_sweep(DgBpShared &S, const DgNode *nd, int
                     const uint4 lo = *reinterpret_cast<const uint4 *>(&nd[n]);
                     const float fin = score[n].y;
                     lens = __builtin_amdgcn_readfirstlane((int)DG_BL_HBM | (int)((lo.y >> 8) & 0xffu) << 16 |
-                                                          (fin == 1.0f ? (int)DG_BL_DONE : 0));
+                                                          (fin >= 1.0f ? (int)DG_BL_DONE : 0));
                 }
                 if ((lens & DG_BL_DONE) || ((lens >> 16) & DG_NF_DELETED)) { sp--; continue; }   // (a deferred vertex is scored when somebody asks for it)
                 int out_len = lens & 0xffff;
@@ -347,7 +351,7 @@ __device__ __forceinline__ void dg_bp_sweep(DgBpShared &S, const DgNode *nd, int
                         else if (S.tag[yd] == d && (S.lens[yd] & DG_BL_DONE) && d >= v_lo) { have = true; sc = S.rscore[yd]; }
                         else {
                             const float2 sg = score[d];
-                            if (sg.y == 1.0f) { have = true; sc = sg.x; }
+                            if (sg.y >= 1.0f) { have = true; sc = (sg.y == 2.0f && xv < 0.5f * DG_BP_NINF) ? xv : sg.x; }   // (2.0: k_bp_xtree)
                         }
                     }
                     const unsigned long long miss = __ballot(valid && !have);
@@ -574,7 +578,7 @@ __global__ __launch_bounds__(64) void k_bp_join(DgParams p) {
     if (dg_failed(p) || dg_tskip(p, t)) return;
     const int lane = threadIdx.x;
     const uint64_t nb = p.node_base[t];
-    const uint32_t *crow = p.gcuts ? p.cuts + (uint64_t)t * (p.seg_max + 2u) : p.cuts_bp + (uint64_t)t * (p.bp_max + 2u);
+    const uint32_t *crow = p.cuts_bp + (uint64_t)t * (p.bp_max + 2u);     // (k_cuts, or k_cuts2 when p.gcuts)
     const uint32_t nseg = crow[0];
     __shared__ uint32_t s_off[65], s_c0[64];
     {
@@ -691,14 +695,46 @@ __global__ __launch_bounds__(64) void k_bp_reset_def(DgParams p) {
     const uint32_t n = dl[0];
     if (n == DG_BP_ONE) return;
     const uint64_t nb = p.node_base[t];
-    for (uint32_t i = threadIdx.x; i < n; i += 64) { p.score[nb + dl[1 + i]] = make_float2(0.0f, 0.0f); p.best[nb + dl[1 + i]] = -1; }
+    for (uint32_t i = threadIdx.x; i < n; i += 64)
+        if (p.score[nb + dl[1 + i]].y != 2.0f) { p.score[nb + dl[1 + i]] = make_float2(0.0f, 0.0f); p.best[nb + dl[1 + i]] = -1; }
+}
+
+// the tree of vertices that lead to exit and nowhere else (see dg_bp_sweep): absolute scores, final flag 2.0
+__global__ __launch_bounds__(64) void k_bp_xtree(DgParams p) {
+    const uint32_t t = blockIdx.x;
+    if (dg_failed(p) || dg_tskip(p, t) || threadIdx.x != 0) return;
+    const uint64_t nb = p.node_base[t];
+    DgNode *nd = p.nodes + nb;
+    const uint32_t *pool = p.pool + p.pool_base[t];
+    const float *tt = p.bp_tt + nb;
+    const int N = (int)p.n_nodes[t];
+    int32_t *q = p.queue + nb;                              // (the merge is over: its FIFO is free)
+    int qh = 0, qt = 0;
+    q[qt++] = N - 1;
+    while (qh < qt) {
+        const int z = q[qh++];
+        const float sz = z == N - 1 ? 0.0f : p.score[nb + z].x;
+        const float td = tt[z];
+        const DgNode nz = nd[z];
+        for (uint32_t i = 0; i < nz.in_len; i++) {
+            const int sv = (int)pool[nz.in_off + i];
+            if (sv == 0) continue;                          // (enter is k_bp_defer's)
+            const DgNode ns = nd[sv];
+            if ((ns.flags & DG_NF_DELETED) || ns.out_len != 1 || p.score[nb + sv].y == 2.0f) continue;
+            const float w = td == DG_TT_TEN ? -10.0f : (float)(int)pool[ns.out_off + 1u] - td;       // :404-408
+            p.score[nb + sv] = make_float2(w + sz, 2.0f);
+            p.best[nb + sv] = z;
+            nd[sv].flags |= DG_NF_DEFER;                    // the segments' streams pass over it
+            if (qt < N) q[qt++] = sv;
+        }
+    }
 }
 
 template <int PASS>
 __global__ __launch_bounds__(64) void k_bp_sweep_g(DgParams p) {
     const uint32_t t = blockIdx.x / p.bp_max, seg = blockIdx.x % p.bp_max;
     if (dg_failed(p) || dg_tskip(p, t)) return;
-    const uint32_t *crow = p.cuts + (uint64_t)t * (p.seg_max + 2u);
+    const uint32_t *crow = p.cuts_bp + (uint64_t)t * (p.bp_max + 2u);
     const uint32_t nseg = crow[0];
     if (seg >= nseg) return;
     const int lane = threadIdx.x;
@@ -723,12 +759,12 @@ __global__ __launch_bounds__(64) void k_bp_sweep_g(DgParams p) {
         const int c_top = last ? -1 : (int)crow[2 + seg];
         const int v_top = last ? N - 1 : c_top - 1;
         if (PASS != 0) {
-            for (int i = c_bot + lane; i <= v_top; i += 64) score[i] = make_float2(0.0f, 0.0f);   // (the pass before left its own)
+            for (int i = c_bot + lane; i <= v_top; i += 64) if (score[i].y != 2.0f) score[i] = make_float2(0.0f, 0.0f);   // (the pass before left its own)
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         }
         float *ab = p.bp_ab + 4ull * blockIdx.x;
         const float ctv = PASS == 0 ? 0.0f : PASS == 1 ? DG_BP_NINF : ab[2];
-        const float xv = PASS == 0 ? DG_BP_NINF : 0.0f;
+        const float xv = PASS == 0 && !last ? DG_BP_NINF : 0.0f;   // (the last piece ends in exit: its scores are absolute at once)
         dg_bp_sweep(S, p.nodes + nb, p.best + nb, score, p.pool + p.pool_base[t], p.bp_tt + nb, v_top, c_bot, c_top,
                     p.stk + (uint64_t)blockIdx.x * p.stk_words, (int)p.stk_words, lane, amax, bad, stuck,
                     ctv, last ? -1 : N - 1, xv, true);
@@ -748,7 +784,7 @@ __global__ __launch_bounds__(64) void k_bp_sweep_g(DgParams p) {
 __global__ __launch_bounds__(64) void k_bp_comb(DgParams p) {
     const uint32_t t = blockIdx.x;
     if (dg_failed(p) || dg_tskip(p, t)) return;
-    const uint32_t *crow = p.cuts + (uint64_t)t * (p.seg_max + 2u);
+    const uint32_t *crow = p.cuts_bp + (uint64_t)t * (p.bp_max + 2u);
     const int nseg = (int)crow[0];
     uint32_t *dl = p.defer + (uint64_t)t * (DG_DEFER_MAX + 1u);
     if (nseg <= 1 || dl[0] == DG_BP_ONE) return;
@@ -761,14 +797,15 @@ __global__ __launch_bounds__(64) void k_bp_comb(DgParams p) {
         const float K = (float)(uint32_t)(p.aln_begin[t + 1] - p.aln_begin[t]);
         const float wmax = K > 10.0f ? K : 10.0f;
         float *ab = p.bp_ab + 4ull * ((uint64_t)t * p.bp_max);
-        float abs_ = ab[4 * (nseg - 1)];                                   // the last piece's first vertex, absolute
+        float abs_ = ab[4 * (nseg - 1)];                                   // the last piece's first vertex, absolute (also when k_bp_xtree scored it)
         if (!(ab[4 * (nseg - 1) + 3] + wmax < 4194304.0f)) redo = true;
         for (int k = nseg - 2; k >= 0; k--) {
             ab[4 * k + 2] = abs_;
             if (!(ab[4 * k + 3] + fabsf(abs_) + wmax < 4194304.0f)) redo = true;
             if (k >= 1) {
+                const float2 sc = p.score[nb + crow[1 + k]];
                 const float viaA = ab[4 * k] + abs_, viaB = ab[4 * k + 1];
-                abs_ = viaA > viaB ? viaA : viaB;
+                abs_ = sc.y == 2.0f ? sc.x : viaA > viaB ? viaA : viaB;       // (a cut inside the exit tree has its score already)
             }
         }
         if (redo) dl[0] = DG_BP_ONE;
@@ -776,7 +813,8 @@ __global__ __launch_bounds__(64) void k_bp_comb(DgParams p) {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     const uint32_t n = dl[0];
     if (n == DG_BP_ONE) return;
-    for (uint32_t i = threadIdx.x; i < n; i += 64) { p.score[nb + dl[1 + i]] = make_float2(0.0f, 0.0f); p.best[nb + dl[1 + i]] = -1; }
+    for (uint32_t i = threadIdx.x; i < n; i += 64)
+        if (p.score[nb + dl[1 + i]].y != 2.0f) { p.score[nb + dl[1 + i]] = make_float2(0.0f, 0.0f); p.best[nb + dl[1 + i]] = -1; }
 }
 
 // the deferred vertices that no sweep was asked for: each once all its successors have their scores
@@ -797,7 +835,7 @@ __global__ __launch_bounds__(64) void k_bp_defer(DgParams p) {
         left = 0;
         for (uint32_t i = 0; i < n; i++) {
             const int v = (int)dl[1 + i];
-            if (score[v].y == 1.0f || (nd[v].flags & DG_NF_DELETED)) continue;
+            if (score[v].y >= 1.0f || (nd[v].flags & DG_NF_DELETED)) continue;
             const DgNode nv = nd[v];
             bool ready = true;
             float mx = 0.0f;
@@ -805,7 +843,7 @@ __global__ __launch_bounds__(64) void k_bp_defer(DgParams p) {
             for (uint32_t e = 0; e < nv.out_len; e++) {
                 const int d = (int)pool[nv.out_off + 2u * e];
                 const float2 sd = score[d];
-                if (sd.y != 1.0f) { ready = false; break; }
+                if (sd.y < 1.0f) { ready = false; break; }
                 const float td = tt[d];
                 const float w = td == DG_TT_TEN ? -10.0f : (float)(int)pool[nv.out_off + 2u * e + 1u] - td;     // :404-408
                 const float ns = w + sd.x;
@@ -822,7 +860,7 @@ __global__ __launch_bounds__(64) void k_bp_defer(DgParams p) {
 __global__ __launch_bounds__(64) void k_bp_walk_g(DgParams p) {
     const uint32_t t = blockIdx.x / p.bp_max, seg = blockIdx.x % p.bp_max;
     if (dg_failed(p) || dg_tskip(p, t)) return;
-    const uint32_t *crow = p.cuts + (uint64_t)t * (p.seg_max + 2u);
+    const uint32_t *crow = p.cuts_bp + (uint64_t)t * (p.bp_max + 2u);
     const uint32_t nseg = crow[0];
     if (seg >= nseg) return;
     const int lane = threadIdx.x;

@@ -1300,6 +1300,38 @@ __global__ __launch_bounds__(64) void k_cuts2(DgParams p) {
             if (found) { if (lane == 0) s_cut[nseg] = found; nseg++; }
         }
         __syncthreads();
+        // bestPath sweeps finer pieces (its waves are light; every piece is swept three times, dg_bp_sweep):
+        // the same conditions, three times as many wanted
+        {
+            uint32_t *brow = p.cuts_bp + (uint64_t)t * (p.bp_max + 2u);
+            const uint32_t smin_b = (p.seg_min + 2u) / 3u;
+            uint32_t want_b = blen / (smin_b ? smin_b : 1u);
+            if (want_b > p.bp_max) want_b = p.bp_max;
+            if (want_b > 64u) want_b = 64u;
+            if (want_b < 1 || !allow) want_b = 1;
+            uint32_t nb_ = 1;
+            if (lane == 0) brow[1] = 0;
+            for (uint32_t s = 1; s < want_b; s++) {
+                const uint32_t p0 = 1u + (uint32_t)((uint64_t)s * blen / want_b);
+                const uint32_t span = blen / want_b / 2u;
+                uint32_t found = 0;
+                for (uint32_t o = 0; o < span && !found; o += 64) {
+                    const uint32_t pos = p0 + o + (uint32_t)lane;
+                    uint32_t v = 0;
+                    bool ok = false;
+                    if (o + (uint32_t)lane < span && pos > pmin && pos <= blen) {
+                        v = bid[pos];
+                        ok = nd[v].weight - 1 == cov[pos];
+                        for (uint32_t d = 0; d < ndead && ok; d++) ok = !(pos > s_dead[2 * d] && pos <= s_dead[2 * d + 1]);
+                    }
+                    const unsigned long long m = __ballot(ok);
+                    if (m) found = (uint32_t)DG_RL(v, __ffsll((long long)m) - 1);
+                }
+                if (found) { if (lane == 0) brow[1 + nb_] = found; nb_++; }
+            }
+            if (lane == 0) brow[0] = nb_;
+        }
+        __syncthreads();
         // shared out-lists: enter's, and those of the vertices the prologue has visited whose out-edges
         // lead into more than one segment; shared in-list: exit's
         DgNode *ndw = p.nodes + p.node_base[t];
@@ -1377,12 +1409,7 @@ __global__ __launch_bounds__(64) void k_cuts2(DgParams p) {
             }
         }
     }
-    // (bestPath sweeps the same pieces: dg_bp_sweep)
-    {
-        uint32_t *crow = p.cuts + (uint64_t)t * (p.seg_max + 2u);
-        if (lane == 0) crow[0] = nseg;
-        for (uint32_t s2 = lane; s2 < nseg; s2 += 64) crow[1 + s2] = skip ? 0u : s_cut[s2];
-    }
+    if (skip && lane == 0) { p.cuts_bp[(uint64_t)t * (p.bp_max + 2u)] = 1u; p.cuts_bp[(uint64_t)t * (p.bp_max + 2u) + 1u] = 0u; }
     // the target's segments, in a row and in order
     __shared__ uint32_t s_base;
     if (lane == 0) {
@@ -1443,7 +1470,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     // what bestPath's segment sweeps must leave alone (DG_NF_DEFER, see dg_bp_sweep): enter, the vertices the
     // prologue visited that have a successor in another segment than their own id, and their ancestors
     {
-        const uint32_t *crow = p.cuts + (uint64_t)t * (p.seg_max + 2u);
+        const uint32_t *crow = p.cuts_bp + (uint64_t)t * (p.bp_max + 2u);     // (bestPath's pieces, k_cuts2)
         const uint32_t nseg = crow[0];
         const int32_t *q0 = p.queue0 + nb;
         const uint32_t nvis = p.pro_state[4u * t + 2u];

@@ -50,7 +50,8 @@ for rnd in range(rounds):
             ctx.close()
             if got != exp:
                 bad += 1
-                print("MISMATCH", desc, kw, shift, min_cov, min_len, trim, flush=True)
+                what = got if isinstance(got, str) else [t for t in range(len(exp)) if got[t] != exp[t]][:8]
+                print("MISMATCH", desc, kw, shift, min_cov, min_len, trim, "->", what, flush=True)
     print(f"round {rnd}: {desc} -c {min_cov} -m {min_len} -t {trim}: ok ({time.time() - t0:.1f} s)", flush=True)
 print("mismatches:", bad)
 sys.exit(1 if bad else 0)
