@@ -910,3 +910,33 @@ def test_cli_polish_rounds(tmp_path):
         assert got.stdout == b"".join(exp), f"--polish {rounds}"
         err[rounds] = e
     assert err[2] < err[0] and err[1] < err[0], err
+
+
+def test_lds_tile_merge_experiment(gpu_ctx_factory, monkeypatch):
+    """The opt-in LDS-tile mergeNodes (DAGCON_TILES=1: a workgroup copies the stretches between cut
+    vertices into LDS and every lane sweeps one; DESIGN.md 'tried and dropped' for why it is not the
+    default) stays exact: consensus and merged graph on full-span pileups, small tiles included."""
+    monkeypatch.setenv("DAGCON_TILES", "1")
+    monkeypatch.setenv("DAGCON_GCUTS", "0")
+    batch = synth.make_batch(12, 3000, 24, seed=610)
+    exp = oracle_batch(batch, 6, 500, 50)
+    for pos in ("16", "64", None):
+        if pos:
+            monkeypatch.setenv("DAGCON_TILE_POS", pos)
+        else:
+            monkeypatch.delenv("DAGCON_TILE_POS")
+        ctx = gpu_ctx_factory(min_cov=6, min_len=500, trim=50)
+        assert ctx.consensus(batch) == exp
+        assert ctx.timings()["merge_segments"] > 20 * batch.n_targets      # really swept in small stretches
+    rng = np.random.default_rng(14)
+    targets = []
+    for i in range(30):
+        tl = int(rng.integers(40, 300))
+        alns, bb = random_target(rng, tl, int(rng.integers(3, 10)), alphabet=[b"AC", b"ACGT"][i % 2],
+                                 ins=float(rng.uniform(0.05, 0.25)), dele=float(rng.uniform(0, 0.12)), full_span=True)
+        targets.append((tl, alns, bb))
+    b2 = batch_from_targets(targets)
+    monkeypatch.setenv("DAGCON_TILE_POS", "8")
+    ctx = gpu_ctx_factory(min_cov=0, min_len=0, trim=0, min_weight=0, flags=capi.FLAG_STOP_AFTER_MERGE)
+    ctx.consensus(b2)
+    _check_graphs(ctx, b2, 0, True, targets=range(0, 30, 3))

@@ -17,4 +17,6 @@ run("config3 shape, one sweep per target", synth.make_batch(8, 50000, 60, seed=7
 tl = np.random.default_rng(5).integers(2000, 40000, 400)
 b5 = synth.make_batch(400, 0, 30, seed=8000, min_span=0.6, tlens=tl, with_backbone=True)
 run("config5 shape: 400 x 2-40 kb x 30x, spans >= 60 %", b5, min_cov=6, min_len=500, trim=10)
+tl = np.random.default_rng(5).integers(2000, 40000, 4000)
+run("config5 shape: 4000 x 2-40 kb x 30x, spans >= 60 %", synth.make_batch(4000, 0, 30, seed=8000, min_span=0.6, tlens=tl, with_backbone=True), min_cov=6, min_len=500, trim=10)
 run("configs[1] at 4000 targets", synth.make_batch(4000, 10000, 40, seed=1000), min_cov=6, min_len=500, trim=50)
