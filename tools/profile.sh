@@ -9,10 +9,10 @@ OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
 CMD="python3 $R/bench.py --steps 3 --warmup 1 --no-cpu --no-verify --no-legs"
-rocprofv3 --kernel-trace --stats -d $OUT/ks -o ks -- $CMD > $OUT/ks.log 2>&1
-rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch -o fetch -- $CMD > $OUT/fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE -d $OUT/write -o write -- $CMD > $OUT/write.log 2>&1
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU -d $OUT/insts -o insts -- $CMD > $OUT/insts.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ks -o ks -- $CMD > $OUT/ks.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o fetch -- $CMD > $OUT/fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -o write -- $CMD > $OUT/write.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU --output-format csv -d $OUT/insts -o insts -- $CMD > $OUT/insts.log 2>&1
 find $OUT -name "*_kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
 find $OUT/fetch -name "*counter_collection.csv" -exec cp {} $OUT/pmc_fetch_counter_collection.csv \;
 find $OUT/write -name "*counter_collection.csv" -exec cp {} $OUT/pmc_write_counter_collection.csv \;
