@@ -75,7 +75,7 @@ typedef struct dagcon_opts {
                               target is swept in up to this many pieces, split at backbone vertices
                               every read passes through (the result does not depend on it).
                               0 = automatic, 1 = one sequential sweep per target, at most 64 */
-    uint32_t min_segment_len; /* shortest backbone stretch given a worker of its own; 0 = default (768) */
+    uint32_t min_segment_len; /* shortest backbone stretch given a worker of its own; 0 = default (768; down to 192 for small batches) */
 } dagcon_opts;
 
 /* Defaults of pbdagcon (main.cpp:181-211): -c 6 -m 500 -t 50. */

@@ -69,7 +69,7 @@ struct Ctx {
     DevBuf d_cns, d_cns_off, d_cns_len, d_seg_first, d_n_seg, d_seg_r0, d_seg_r1, d_st;
 
     uint64_t norm_cap = 0, node_cap = 0, pool_cap = 0, cns_cap = 0, seg_cap = 0;
-    uint32_t stk_words = 4096, growth_pct = 100, seg_max = 8, bp_max = 16, seg_env = 0;    // (scratch per target and segment: grown x4 and re-run on DG_E_STACK)
+    uint32_t stk_words = 4096, growth_pct = 100, seg_max = 8, bp_max = 16, seg_env = 0, seg_min = 768;    // (scratch per target and segment: grown x4 and re-run on DG_E_STACK)
     uint32_t sh_log = 16;                           // slots per segment behind enter's / exit's list (x2 on DG_E_LOG_OVF)
     bool full_span = false;                         // (nearly) every alignment of the batch covers its whole target
     uint32_t gcuts = 1;                             // partial-span cuts: prologue + worklist + epilogue (DAGCON_GCUTS=0: off)
@@ -226,7 +226,7 @@ void fill_params(Ctx *c, DgParams &p) {
     // the prefetch wave pays while the chip has idle wave slots; past ~1.5 workers per SIMD the
     // workers hide each other's latency and it only takes issue slots from them
     { const char *e = getenv("DAGCON_PF_AHEAD"); p.pf_ahead = e ? (uint32_t)atoi(e) : (c->expected_workers >= 4096 ? 0u : 48u); }
-    p.seg_max = c->seg_max; p.seg_min = c->opts.min_segment_len ? c->opts.min_segment_len : 768u; p.cuts = (uint32_t *)c->d_cuts.p; p.bp_max = c->bp_max; p.cuts_bp = (uint32_t *)c->d_cuts_bp.p; p.bp_stat = (float *)c->d_bp_stat.p; p.bp_len = (uint32_t *)c->d_bp_len.p;
+    p.seg_max = c->seg_max; p.seg_min = c->seg_min; p.cuts = (uint32_t *)c->d_cuts.p; p.bp_max = c->bp_max; p.cuts_bp = (uint32_t *)c->d_cuts_bp.p; p.bp_stat = (float *)c->d_bp_stat.p; p.bp_len = (uint32_t *)c->d_bp_len.p;
     p.gcuts = c->gcuts; p.sh_log = c->sh_log;
     p.rd_s = (uint32_t *)c->d_rd.p; p.rd_e = p.rd_s + c->A; p.rd_lead = p.rd_e + c->A; p.rd_trail = p.rd_lead + c->A;
     p.pro_state = (uint32_t *)c->d_pro_state.p; p.sh_cnt = (uint32_t *)c->d_sh_cnt.p;
@@ -417,10 +417,10 @@ int dagcon_upload(dagcon_ctx *ctx, const dagcon_batch *b) {
 
     c->T = T;
     // merge workers per target: about one chip's worth of resident waves (8 per SIMD x 1024
-    // SIMDs) over the batch, never fewer than 8 nor more than 32 per target
+    // SIMDs) over the batch, never fewer than 8 nor more than 64 per target
     if (c->opts.max_segments) c->seg_max = c->opts.max_segments > 64u ? 64u : c->opts.max_segments;
     else if (c->seg_env) c->seg_max = c->seg_env;
-    else { uint32_t sm = T ? 8192u / T : 8u; c->seg_max = sm < 8u ? 8u : sm > 32u ? 32u : sm; }
+    else { uint32_t sm = T ? 8192u / T : 8u; c->seg_max = sm < 8u ? 8u : sm > 64u ? 64u : sm; }
     // bestPath is swept in three times as many pieces: its waves are light (one piece = one
     // sequential sweep when that is asked for)
     c->bp_max = c->seg_max == 1 ? 1u : std::min(64u, 3u * c->seg_max);
@@ -490,6 +490,10 @@ int dagcon_upload(dagcon_ctx *ctx, const dagcon_batch *b) {
     // cuts for partial-span pileups (prologue + worklist + epilogue): where the reads are full-span the cut
     // vertices every read passes through are the same ones, found without that machinery
     c->full_span = n_whole == (uint64_t)c->h_aln_len.size();
+    // shortest stretch worth a worker: 768 positions when that already fills the chip, shorter (down to 192)
+    // for small batches, whose waves would otherwise be few and long
+    c->seg_min = c->opts.min_segment_len;
+    if (!c->seg_min) c->seg_min = (uint32_t)std::min<uint64_t>(768, std::max<uint64_t>(192, c->sum_bb / 8192));
     c->gcuts = c->full_span ? 0u : 1u;
     if (const char *e = getenv("DAGCON_GCUTS")) c->gcuts = atoi(e) ? 1u : 0u;
     if (c->gcuts) c->tile_list_cap = std::max<uint32_t>(c->tile_list_cap, (uint32_t)std::min<uint64_t>((uint64_t)T * c->seg_max + 64, 0x0FFFFFFFull));

@@ -204,13 +204,18 @@ def test_segmented_sweeps_are_exact(gpu_ctx_factory):
         exp = oracle_batch(batch, 6, 500, trim)
         nseg = {}
         for ms, flags in ((1, 0), (3, 0), (8, 0), (32, 0), (8, capi.FLAG_DEBUG_RESWEEP)):
-            ctx = gpu_ctx_factory(min_cov=6, min_len=500, trim=trim, max_segments=ms, flags=flags)
+            ctx = gpu_ctx_factory(min_cov=6, min_len=500, trim=trim, max_segments=ms, flags=flags,
+                                  min_segment_len=768)
             assert ctx.consensus(batch) == exp, f"max_segments={ms} flags={flags}"
             nseg[ms] = ctx.timings()["merge_segments"]
         assert nseg[1] == batch.n_targets
         if batch is full:
             assert nseg[8] == 6 * 7 and nseg[3] == 6 * 3       # 6000 / 768 = 7 stretches wanted and found
         assert nseg[32] >= nseg[8] >= nseg[3] >= nseg[1]
+        # the default: shorter stretches (down to 192 positions) when the batch is too small to fill the chip
+        ctx = gpu_ctx_factory(min_cov=6, min_len=500, trim=trim)
+        assert ctx.consensus(batch) == exp
+        assert ctx.timings()["merge_segments"] >= nseg[32]
 
 
 @pytest.mark.parametrize("seed", [11, 12])

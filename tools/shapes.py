@@ -13,6 +13,7 @@ def run(name, b, **kw):
           "bases", bases, f"{bases / t['ms_total'] / 1e3:.1f} M bases/s", flush=True)
     ctx.close()
 run("config3 shape: 8 x 50 kb x 60x full span", synth.make_batch(8, 50000, 60, seed=7000), min_cov=8, min_len=500, trim=50)
+run("config3 shape: 128 x 50 kb x 60x full span (chip full)", synth.make_batch(128, 50000, 60, seed=7000), min_cov=8, min_len=500, trim=50)
 run("config3 shape, one sweep per target", synth.make_batch(8, 50000, 60, seed=7000), min_cov=8, min_len=500, trim=50, max_segments=1)
 tl = np.random.default_rng(5).integers(2000, 40000, 400)
 b5 = synth.make_batch(400, 0, 30, seed=8000, min_span=0.6, tlens=tl, with_backbone=True)
