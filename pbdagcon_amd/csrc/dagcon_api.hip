@@ -370,7 +370,7 @@ int dagcon_create(const dagcon_opts *opts, dagcon_ctx **out) {
     }
     memset(&c->tm, 0, sizeof c->tm);
     memset(&c->h_st, 0, sizeof c->h_st);
-    if (hipSetDevice(c->device) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess) {
+    if (hipSetDevice(c->device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
         delete c;
         return DAGCON_ERR_NO_DEVICE;
     }
@@ -638,9 +638,16 @@ int dagcon_sync(dagcon_ctx *ctx) {
     return DAGCON_OK;
 }
 
+// device -> host on the context's own stream.  (hipMemcpy would go through the null stream, and the stream is
+// non-blocking so that a second context on the same GPU is not serialised against this one's copies.)
+static hipError_t d2h(Ctx *c, void *dst, const void *src, size_t bytes) {
+    hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream);
+    return e != hipSuccess ? e : hipStreamSynchronize(c->stream);
+}
+
 static int read_status(Ctx *c) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipMemcpy(&c->h_st, c->d_st.p, sizeof(DgStatus), hipMemcpyDeviceToHost));
+    HIPCHK(c, d2h(c, &c->h_st, c->d_st.p, sizeof(DgStatus)));
     return DAGCON_OK;
 }
 
@@ -682,7 +689,7 @@ int dagcon_fetch(dagcon_ctx *ctx, dagcon_results *res) {
     const uint32_t T = c->T;
     // per-target outcome (ABI 2): a failure is confined to its target
     c->r_tfail.assign(T, 0); c->r_status.assign(T, DAGCON_OK);
-    if (T) HIPCHK(c, hipMemcpy(c->r_tfail.data(), c->d_tfail.p, (size_t)T * 4, hipMemcpyDeviceToHost));
+    if (T) HIPCHK(c, d2h(c, c->r_tfail.data(), c->d_tfail.p, (size_t)T * 4));
     uint32_t n_failed = 0;
     c->err.clear();
     for (uint32_t t = 0; t < T; t++) {
@@ -711,15 +718,15 @@ int dagcon_fetch(dagcon_ctx *ctx, dagcon_results *res) {
     c->r_blob[nb] = 0;
     const bool full = !(c->opts.flags & (DAGCON_FLAG_STOP_AFTER_BUILD | DAGCON_FLAG_STOP_AFTER_MERGE));
     if (T && full) {
-        HIPCHK(c, hipMemcpy(c->r_cns_off.data(), c->d_cns_off.p, (size_t)T * 8, hipMemcpyDeviceToHost));
-        HIPCHK(c, hipMemcpy(c->r_cns_len.data(), c->d_cns_len.p, (size_t)T * 4, hipMemcpyDeviceToHost));
-        HIPCHK(c, hipMemcpy(c->r_seg_first.data(), c->d_seg_first.p, (size_t)T * 8, hipMemcpyDeviceToHost));
-        HIPCHK(c, hipMemcpy(c->r_n_seg.data(), c->d_n_seg.p, (size_t)T * 4, hipMemcpyDeviceToHost));
+        HIPCHK(c, d2h(c, c->r_cns_off.data(), c->d_cns_off.p, (size_t)T * 8));
+        HIPCHK(c, d2h(c, c->r_cns_len.data(), c->d_cns_len.p, (size_t)T * 4));
+        HIPCHK(c, d2h(c, c->r_seg_first.data(), c->d_seg_first.p, (size_t)T * 8));
+        HIPCHK(c, d2h(c, c->r_n_seg.data(), c->d_n_seg.p, (size_t)T * 4));
         if (nseg) {
-            HIPCHK(c, hipMemcpy(c->r_tmp0.data(), c->d_seg_r0.p, nseg * 4, hipMemcpyDeviceToHost));
-            HIPCHK(c, hipMemcpy(c->r_tmp1.data(), c->d_seg_r1.p, nseg * 4, hipMemcpyDeviceToHost));
+            HIPCHK(c, d2h(c, c->r_tmp0.data(), c->d_seg_r0.p, nseg * 4));
+            HIPCHK(c, d2h(c, c->r_tmp1.data(), c->d_seg_r1.p, nseg * 4));
         }
-        if (nb) HIPCHK(c, hipMemcpy(c->r_blob, c->d_cns.p, nb, hipMemcpyDeviceToHost));
+        if (nb) HIPCHK(c, d2h(c, c->r_blob, c->d_cns.p, nb));
     }
     c->r_seg_begin.assign(T + 1, 0);
     c->r_range0.clear(); c->r_range1.clear(); c->r_seq_off.clear(); c->r_seq_len.clear();
@@ -762,7 +769,7 @@ int dagcon_debug_counters(dagcon_ctx *ctx, unsigned long long *out8) {
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     DgStatus st;
-    HIPCHK(c, hipMemcpy(&st, c->d_st.p, sizeof st, hipMemcpyDeviceToHost));
+    HIPCHK(c, d2h(c, &st, c->d_st.p, sizeof st));
     for (int i = 0; i < 16; i++) out8[i] = st.dbg[i];
     return DAGCON_OK;
 }
@@ -830,16 +837,16 @@ static int normalize_impl(Ctx *c, dagcon_ctx *ctx, uint32_t n, const uint32_t *a
     std::vector<uint64_t> noff(n);
     std::vector<uint32_t> lo(n), hi(n), st(n);
     if (n) {
-        HIPCHK(c, hipMemcpy(noff.data(), c->d_norm_off.p, (size_t)n * 8, hipMemcpyDeviceToHost));
-        HIPCHK(c, hipMemcpy(lo.data(), c->d_n_lo.p, (size_t)n * 4, hipMemcpyDeviceToHost));
-        HIPCHK(c, hipMemcpy(hi.data(), c->d_n_hi.p, (size_t)n * 4, hipMemcpyDeviceToHost));
-        HIPCHK(c, hipMemcpy(st.data(), c->d_n_start.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+        HIPCHK(c, d2h(c, noff.data(), c->d_norm_off.p, (size_t)n * 8));
+        HIPCHK(c, d2h(c, lo.data(), c->d_n_lo.p, (size_t)n * 4));
+        HIPCHK(c, d2h(c, hi.data(), c->d_n_hi.p, (size_t)n * 4));
+        HIPCHK(c, d2h(c, st.data(), c->d_n_start.p, (size_t)n * 4));
     }
     std::vector<uint16_t> cols;
     for (uint32_t a = 0; a < n; a++) {
         const uint32_t m = hi[a] - lo[a];
         cols.resize(m);
-        if (m) HIPCHK(c, hipMemcpy(cols.data(), (const uint16_t *)c->d_norm.p + noff[a] + lo[a], (size_t)m * 2, hipMemcpyDeviceToHost));
+        if (m) HIPCHK(c, d2h(c, cols.data(), (const uint16_t *)c->d_norm.p + noff[a] + lo[a], (size_t)m * 2));
         for (uint32_t i = 0; i < m; i++) {
             qout[out_off[a] + i] = (char)(cols[i] & 0xff);
             tout[out_off[a] + i] = (char)(cols[i] >> 8);
@@ -929,9 +936,9 @@ int dagcon_align(dagcon_ctx *ctx, uint32_t n, const uint64_t *q_off, const uint3
         HIPCHK(c, hipStreamSynchronize(s));       // (the direction buffer is reused by the next group)
         first += cnt;
     }
-    HIPCHK(c, hipMemcpy(aln_len, dlen.p, (size_t)n * 4, hipMemcpyDeviceToHost));
-    HIPCHK(c, hipMemcpy(qaln, dqa.p, out_bytes, hipMemcpyDeviceToHost));
-    HIPCHK(c, hipMemcpy(taln, dta.p, out_bytes, hipMemcpyDeviceToHost));
+    HIPCHK(c, d2h(c, aln_len, dlen.p, (size_t)n * 4));
+    HIPCHK(c, d2h(c, qaln, dqa.p, out_bytes));
+    HIPCHK(c, d2h(c, taln, dta.p, out_bytes));
     // the kernel fills each pair's room from the back (it walks the alignment from its end)
     for (uint32_t a = 0; a < n; a++) {
         const uint64_t cap = (uint64_t)q_len[a] + t_len[a], len = aln_len[a];
@@ -967,20 +974,20 @@ int dagcon_debug_graph(dagcon_ctx *ctx, uint32_t target, dagcon_graph_dump *out)
     HIPCHK(c, hipStreamSynchronize(c->stream));
     uint64_t nb = 0, pb = 0;
     uint32_t N = 0, psz = 0;
-    HIPCHK(c, hipMemcpy(&nb, (uint64_t *)c->d_node_base.p + target, 8, hipMemcpyDeviceToHost));
-    HIPCHK(c, hipMemcpy(&pb, (uint64_t *)c->d_pool_base.p + target, 8, hipMemcpyDeviceToHost));
-    HIPCHK(c, hipMemcpy(&N, (uint32_t *)c->d_n_nodes.p + target, 4, hipMemcpyDeviceToHost));
-    HIPCHK(c, hipMemcpy(&psz, (uint32_t *)c->d_pool_top.p + target, 4, hipMemcpyDeviceToHost));
+    HIPCHK(c, d2h(c, &nb, (uint64_t *)c->d_node_base.p + target, 8));
+    HIPCHK(c, d2h(c, &pb, (uint64_t *)c->d_pool_base.p + target, 8));
+    HIPCHK(c, d2h(c, &N, (uint32_t *)c->d_n_nodes.p + target, 4));
+    HIPCHK(c, d2h(c, &psz, (uint32_t *)c->d_pool_top.p + target, 4));
     if (!c->h_tactive[target]) N = 0;
     std::vector<DgNode> nd(N);
     std::vector<uint32_t> pool(psz);
     std::vector<int32_t> cov(c->h_tlen[target] + 2, 0);
     c->g_weight.assign(N, 0); c->g_cov.assign(N, 0);
     if (N) {
-        HIPCHK(c, hipMemcpy(nd.data(), (DgNode *)c->d_nodes.p + nb, (size_t)N * sizeof(DgNode), hipMemcpyDeviceToHost));
+        HIPCHK(c, d2h(c, nd.data(), (DgNode *)c->d_nodes.p + nb, (size_t)N * sizeof(DgNode)));
         const uint32_t nbb = c->h_tlen[target] + 2;
-        HIPCHK(c, hipMemcpy(cov.data(), (int32_t *)c->d_cov.p + c->h_bbv_base[target], (size_t)nbb * 4, hipMemcpyDeviceToHost));
-        if (psz) HIPCHK(c, hipMemcpy(pool.data(), (uint32_t *)c->d_pool.p + pb, (size_t)psz * 4, hipMemcpyDeviceToHost));
+        HIPCHK(c, d2h(c, cov.data(), (int32_t *)c->d_cov.p + c->h_bbv_base[target], (size_t)nbb * 4));
+        if (psz) HIPCHK(c, d2h(c, pool.data(), (uint32_t *)c->d_pool.p + pb, (size_t)psz * 4));
     }
     c->g_base.assign(N, 0); c->g_deleted.assign(N, 0); c->g_backbone.assign(N, 0); c->g_bbpos.assign(N, 0);
     c->g_out_begin.assign(N + 1, 0); c->g_in_begin.assign(N + 1, 0);

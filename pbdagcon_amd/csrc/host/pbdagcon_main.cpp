@@ -27,6 +27,7 @@
 #include <condition_variable>
 #include <mutex>
 #include <string>
+#include <chrono>
 #include <thread>
 #include <vector>
 
@@ -44,6 +45,7 @@ struct Opts {
     bool align = false, verbose = false, dump = false;
     std::vector<int> devices{0};       // --devices: one consensus worker (thread + context) per GPU
     int pinned = -1;                   // --pinned 0|1: page-locked blobs (-1: when the input is several batches long)
+    unsigned contexts = 0;             // --contexts N: consensus workers per GPU (0: two when the input is several batches long)
     unsigned polish = 0;               // --polish N (with -a): N more rounds with the consensus as the new backbone
     size_t batch_targets = 256;        // small enough that parsing and the GPU overlap on mid-size inputs
     size_t batch_bytes = 1ull << 30;
@@ -67,6 +69,8 @@ void usage(FILE *f) {
             "                      backbone sequence to iteratively improve the consensus quality')\n"
             "  --devices LIST      GPUs to use, e.g. 0,1,2,3 (default 0): one consensus worker per GPU, batches of\n"
             "                      targets dealt round-robin, records still printed in input order\n"
+            "  --contexts N        consensus workers (thread + context) per GPU, 1..4: a batch's upload and formatting run\n"
+            "                      beside another batch's kernels (default: 2 for inputs of several batches, else 1)\n"
             "  <input>             BLASR -m 5 file (.pre with -a) sorted by target, or - for stdin\n"
             "  version 0.3 (dagcon-mi355x)\n");
 }
@@ -98,6 +102,7 @@ int parse_args(int argc, char **argv, Opts &o) {
         else if (a == "--slab-bytes") { unsigned v = 0; if (!need(&v)) return 2; o.slab_bytes = v; }   // test hook
         else if (a == "--batch-targets") { unsigned v = 0; if (!need(&v) || !v) return 2; o.batch_targets = v; }
         else if (a == "--polish") { if (!need(&o.polish)) return 2; }
+        else if (a == "--contexts") { if (!need(&o.contexts) || !o.contexts || o.contexts > 4) { fprintf(stderr, "PARSE ERROR: --contexts takes 1..4\n"); return 2; } }
         else if (a == "--pinned") { unsigned v = 0; if (!need(&v)) return 2; o.pinned = v ? 1 : 0; }
         else if (a == "--devices") {
             if (i + 1 >= argc) { fprintf(stderr, "PARSE ERROR: --devices needs a list such as 0,1,2\n"); return 2; }
@@ -185,6 +190,11 @@ struct Batch {
     void clear() { ids.clear(); tlen.clear(); start.clear(); len.clear(); len2.clear(); begin.assign(1, 0); off.clear(); off2.clear(); strand.clear(); q.n = 0; t.n = 0; out.clear(); }
 };
 
+bool g_timing = false;                                    // PBDAGCON_TIMING
+std::mutex g_tmu;
+double g_t_upload = 0, g_t_run = 0, g_t_fetch = 0;
+double wall() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
 // one batch through the device; the records go to b.out (main.cpp:141-143), warnings to stderr
 int flush(dagcon_ctx *ctx, Batch &b, const Opts &o) {
     if (b.ids.empty()) return 0;
@@ -229,7 +239,19 @@ int flush(dagcon_ctx *ctx, Batch &b, const Opts &o) {
         db.qstr = qa.data(); db.tstr = ta.data(); db.blob_bytes = tot;
     }
     dagcon_results r;
-    int rc = dagcon_consensus(ctx, &db, &r);
+    int rc;
+    if (g_timing) {                                       // the three steps of dagcon_consensus, timed apart
+        const double t0 = wall();
+        rc = dagcon_upload(ctx, &db);
+        const double t1 = wall();
+        if (rc == DAGCON_OK) rc = dagcon_run(ctx);
+        if (rc == DAGCON_OK) rc = dagcon_sync(ctx);
+        const double t2 = wall();
+        if (rc == DAGCON_OK) rc = dagcon_fetch(ctx, &r);
+        const double t3 = wall();
+        std::lock_guard<std::mutex> lk(g_tmu);
+        g_t_upload += t1 - t0; g_t_run += t2 - t1; g_t_fetch += t3 - t2;
+    } else rc = dagcon_consensus(ctx, &db, &r);
     if (rc != DAGCON_OK) {
         fprintf(stderr, "pbdagcon: consensus failed (%d): %s\n", rc, dagcon_last_error(ctx));
         return 1;
@@ -361,6 +383,12 @@ int flush(dagcon_ctx *ctx, Batch &b, const Opts &o) {
 int main(int argc, char **argv) {
     Opts o;
     if (int rc = parse_args(argc, argv, o)) return rc;
+    // PBDAGCON_TIMING=1: where the wall time of the run went, on stderr (seconds)
+    const bool timing = getenv("PBDAGCON_TIMING") != nullptr;
+    g_timing = timing;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_main = now();
+    double t_index = 0, t_fill = 0, t_wait = 0, t_create = 0, t_flush = 0, t_print = 0, t_parse_end = 0, t_joined = 0;
     // ---- input: mmap a file, or slurp stdin ----
     const char *data = nullptr;
     size_t size = 0;
@@ -388,7 +416,12 @@ int main(int argc, char **argv) {
     // ---- consensus workers: one thread + context per GPU (the reference starts its N consensus
     // workers itself too, main.cpp:251-274); batches are taken in input order from one queue, their
     // records are printed in input order by whoever completes the next one in line ----
-    const size_t ndev = o.devices.size();
+    // (two contexts per GPU: one batch's host-to-device copy, host preparation and record formatting go on
+    // beside the other's kernels)
+    const unsigned per_dev = o.contexts ? o.contexts : (size > 512ull << 20 ? 2u : 1u);
+    std::vector<int> worker_dev;
+    for (unsigned k = 0; k < per_dev; k++) for (int d : o.devices) worker_dev.push_back(d);
+    const size_t ndev = worker_dev.size();
     const size_t nbuf = ndev + 1;                          // the parser fills one while the others are on GPUs
     std::vector<Batch> bufs(nbuf);
     std::mutex mu;
@@ -409,10 +442,12 @@ int main(int argc, char **argv) {
             dagcon_default_opts(&dopt);
             dopt.min_cov = o.min_cov; dopt.min_len = o.min_len; dopt.trim = o.trim;
             dopt.min_weight = (int32_t)o.min_cov;          // main.cpp:261,279 (quirk Q1)
-            dopt.device = o.devices[w];
+            dopt.device = worker_dev[w];
+            const double tc0 = now();
             int rc = dagcon_create(&dopt, &ctx);
+            if (w == 0) t_create = now() - tc0;
             if (rc != DAGCON_OK) {
-                fprintf(stderr, "pbdagcon: no usable MI355X as device %d (dagcon_create = %d); there is no CPU fallback\n", o.devices[w], rc);
+                fprintf(stderr, "pbdagcon: no usable MI355X as device %d (dagcon_create = %d); there is no CPU fallback\n", worker_dev[w], rc);
                 std::lock_guard<std::mutex> lk(mu);
                 worker_status = 1;
                 cv.notify_all();
@@ -427,9 +462,12 @@ int main(int argc, char **argv) {
                     if (work.empty()) break;
                     b = work.front(); work.erase(work.begin());
                 }
+                const double tf0 = now();
                 const int st = flush(ctx, *b, o);
+                const double tf = now() - tf0;
                 {
                     std::unique_lock<std::mutex> lk(mu);
+                    t_flush += tf;
                     if (st) worker_status = st;
                     done.push_back(b);
                     // print what is next in line (this batch and any that were waiting on it)
@@ -439,7 +477,7 @@ int main(int argc, char **argv) {
                             if (done[i]->seq != print_seq) continue;
                             Batch *d = done[i];
                             done.erase(done.begin() + i);
-                            fwrite(d->out.data(), 1, d->out.size(), stdout);
+                            { const double tp0 = now(); fwrite(d->out.data(), 1, d->out.size(), stdout); t_print += now() - tp0; }
                             d->clear();
                             free_list.push_back(d);
                             print_seq++;
@@ -477,7 +515,9 @@ int main(int argc, char **argv) {
             work.push_back(bp);
         }
         cv.notify_all();
+        const double tw0 = now();
         bp = acquire();
+        t_wait += now() - tw0;
         return bp ? 0 : 1;
     };
 
@@ -497,7 +537,7 @@ int main(int argc, char **argv) {
     // whole file has been indexed; the records of a slab's last (possibly unfinished) target
     // are carried into the next slab
     const size_t slab_bytes = o.slab_bytes ? o.slab_bytes : std::max<size_t>(o.batch_bytes, 256u << 20);
-    size_t slab_pos = 0;
+    size_t slab_pos = 0, unmapped = 0;
     unsigned long long n_rec_before = 0;
     bool had_error = false;
     int status = 0;
@@ -621,7 +661,7 @@ int main(int argc, char **argv) {
             const char *nl = (const char *)memchr(data + s1, '\n', size - s1);
             s1 = nl ? (size_t)(nl - data) + 1 : size;
         }
-        index_slab(slab_pos, s1);
+        { const double t0 = now(); index_slab(slab_pos, s1); t_index += now() - t0; }
         slab_pos = s1;
         const bool eof = slab_pos >= size || had_error;
         // all but the last target of the slab (it may go on in the next one)
@@ -641,7 +681,7 @@ int main(int argc, char **argv) {
             if (last || (new_target && x > rb && (b.ids.size() >= o.batch_targets || bytes >= o.batch_bytes))) {
                 if (x > rb) {
                     b.begin.push_back(b.start.size());
-                    fill_strings(b, rb, x, bytes, bytes2);
+                    { const double t0 = now(); fill_strings(b, rb, x, bytes, bytes2); t_fill += now() - t0; }
                     if (o.dump) {
                         for (size_t y = rb; y < x; y++) {
                             const Rec &r = *recs[y];
@@ -673,10 +713,31 @@ int main(int argc, char **argv) {
         std::vector<Rec> next_carry;
         for (size_t x = n_use; x < recs.size(); x++) next_carry.push_back(*recs[x]);
         carry.swap(next_carry);
+        // the text in front of the first carried record is finished with: its page-table entries go now, while the
+        // GPU works, instead of all at once at the end (0.3 s for 26 GB of text)
+        if (map) {
+            const size_t dead = carry.empty() ? slab_pos : (size_t)(carry[0].name - data);
+            const size_t upto = dead & ~(size_t)((2u << 20) - 1);
+            if (upto > unmapped) {
+                // MADV_DONTNEED takes the address-space lock shared (munmap takes it exclusively and would stall the
+                // workers' page faults and the driver's pinning): the threads drop a share of the range each
+                const size_t n2m = (upto - unmapped) >> 21;
+                auto drop = [&](unsigned k) {
+                    const size_t a = unmapped + ((n2m * k / nthr) << 21), e = unmapped + ((n2m * (k + 1) / nthr) << 21);
+                    if (e > a) madvise((char *)map + a, e - a, MADV_DONTNEED);
+                };
+                std::vector<std::thread> th;
+                for (unsigned k = 1; k < nthr; k++) th.emplace_back(drop, k);
+                drop(0);
+                for (auto &x : th) x.join();
+                unmapped = upto;
+            }
+        }
         if (eof && carry.empty()) break;
         if (eof) slab_pos = size;
     }
     if (had_error) status = 1;
+    t_parse_end = now();
 #undef b
     if (!o.dump) {
         {
@@ -689,8 +750,14 @@ int main(int argc, char **argv) {
         cv.notify_all();
         for (auto &w : workers) w.join();
     }
+    t_joined = now();
     for (auto &x : bufs) { x.q.release(); x.t.release(); }
     if (map) munmap(map, size);
     fflush(stdout);
+    if (timing)
+        fprintf(stderr, "pbdagcon timing: total %.3f = parse loop %.3f (index %.3f  fill %.3f  wait-for-buffer %.3f) + drain %.3f + teardown %.3f | "
+                "worker 0: create %.3f; all workers: flush %.3f (upload %.3f  run %.3f  fetch %.3f)  print %.3f\n",
+                now() - t_main, t_parse_end - t_main, t_index, t_fill, t_wait, t_joined - t_parse_end, now() - t_joined, t_create, t_flush,
+                g_t_upload, g_t_run, g_t_fetch, t_print);
     return status;
 }
