@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <chrono>
 #include <vector>
 
 #include "../../include/dagcon.h"
@@ -65,7 +66,7 @@ struct Ctx {
     DevBuf d_matA, d_matD, d_matC, d_cov, d_gcount, d_gbase, d_bid;
     DevBuf d_nodes, d_best, d_queue, d_score, d_cns_tmp, d_bp_tt;
     DevBuf d_pool, d_stk, d_cuts, d_cuts_bp, d_bp_stat, d_bp_len, d_nextcut, d_tile_list, d_rd, d_pro_state, d_sh_cnt, d_seg_done, d_wl_first, d_queue0, d_bp_end, d_bp_ab, d_defer, d_cns_tmp0;
-    DevBuf d_al[12];                                // dagcon_align: blobs, offsets, outputs, directions
+    DevBuf d_al[13];                                // dagcon_align: blobs, offsets, outputs, directions, launch order
     DevBuf d_cns, d_cns_off, d_cns_len, d_seg_first, d_n_seg, d_seg_r0, d_seg_r1, d_st;
 
     uint64_t norm_cap = 0, node_cap = 0, pool_cap = 0, cns_cap = 0, seg_cap = 0;
@@ -909,44 +910,82 @@ int dagcon_align(dagcon_ctx *ctx, uint32_t n, const uint64_t *q_off, const uint3
     HIPCHK(c, hipMemcpyAsync(dql.p, q_len, (size_t)n * 4, hipMemcpyHostToDevice, s));
     HIPCHK(c, hipMemcpyAsync(dtl.p, t_len, (size_t)n * 4, hipMemcpyHostToDevice, s));
     HIPCHK(c, hipMemcpyAsync(doo.p, out_off, (size_t)n * 8, hipMemcpyHostToDevice, s));
-    // direction words (64 per row, q_len + 1 rows per pair) for as many pairs at a time as fit the budget
+    // direction words (64 per row; dg_align_rows: q_len + 1 rows per pair and room for the walk's codes) for as many
+    // pairs at a time as fit the budget; inside a group one launch per kernel instance (cells per lane)
+    // (one wave per pair and ~1 us per row: what counts is how many pairs are in flight, so the budget is generous:
+    // a third of the free device memory, 96 GB at most; 8,192 waves fill the chip)
     uint64_t budget_rows = (6ull << 30) / 256ull;
+    {
+        size_t mfree = 0, mtotal = 0;
+        if (hipMemGetInfo(&mfree, &mtotal) == hipSuccess) {
+            const uint64_t have = (uint64_t)mfree + (uint64_t)ddir.cap;      // (the buffer of the last call is ours to reuse)
+            budget_rows = std::min<uint64_t>(96ull << 30, std::max<uint64_t>(1ull << 30, have / 3)) / 256ull;
+        }
+    }
     if (const char *e = getenv("DAGCON_ALIGN_ROWS")) { const long long v = atoll(e); if (v >= 1) budget_rows = (uint64_t)v; }   // test knob
+    const bool t_dbg = getenv("DAGCON_ALIGN_TIMING") != nullptr;
+    if (t_dbg) HIPCHK(c, hipStreamSynchronize(s));
+    double t_grp = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    DevBuf &didx = c->d_al[12];
+    ENSURE(c, didx, (size_t)n * 4);
+    std::vector<uint32_t> order(n);
     uint32_t first = 0;
     while (first < n) {
         uint64_t rows = 0;
         uint32_t cnt = 0;
         while (first + cnt < n) {
-            const uint64_t r = (uint64_t)q_len[first + cnt] + 1;
+            const uint64_t r = dg_align_rows(q_len[first + cnt], t_len[first + cnt]);
             if (cnt && rows + r > budget_rows) break;
             dir_off[first + cnt] = rows;
             rows += r; cnt++;
         }
         ENSURE(c, ddir, rows * 256ull);
         HIPCHK(c, hipMemcpyAsync((uint64_t *)ddo.p + first, dir_off.data() + first, (size_t)cnt * 8, hipMemcpyHostToDevice, s));
+        // the group's pairs by kernel instance, the long ones first inside each
+        static const uint32_t kinds[6] = {2, 4, 6, 8, 12, 16};
+        uint32_t fill = 0, kbeg[7];
+        for (int k = 0; k < 6; k++) {
+            kbeg[k] = fill;
+            for (uint32_t x = 0; x < cnt; x++)
+                if (dg_align_cells(q_len[first + x], t_len[first + x]) == kinds[k]) order[first + fill++] = first + x;
+            std::stable_sort(order.begin() + first + kbeg[k], order.begin() + first + fill,
+                             [&](uint32_t x, uint32_t y) { return q_len[x] > q_len[y]; });
+        }
+        kbeg[6] = fill;
+        HIPCHK(c, hipMemcpyAsync((uint32_t *)didx.p + first, order.data() + first, (size_t)cnt * 4, hipMemcpyHostToDevice, s));
         DgAlignParams ap;
         ap.q = (const uint8_t *)dq.p; ap.t = (const uint8_t *)dt.p;
         ap.q_off = (const uint64_t *)dqo.p; ap.t_off = (const uint64_t *)dto.p;
         ap.q_len = (const uint32_t *)dql.p; ap.t_len = (const uint32_t *)dtl.p;
         ap.out_off = (const uint64_t *)doo.p; ap.qaln = (uint8_t *)dqa.p; ap.taln = (uint8_t *)dta.p;
         ap.aln_len = (uint32_t *)dlen.p; ap.dirs = (uint32_t *)ddir.p; ap.dir_off = (const uint64_t *)ddo.p;
-        ap.first = first; ap.n = cnt;
-        hipLaunchKernelGGL(k_align_banded, dim3(cnt), dim3(64), 0, s, ap);
-        HIPCHK(c, hipGetLastError());
+        for (int k = 0; k < 6; k++) {
+            const uint32_t nk = kbeg[k + 1] - kbeg[k];
+            if (!nk) continue;
+            ap.idx = (const uint32_t *)didx.p + first + kbeg[k]; ap.n = nk;
+            switch (kinds[k]) {
+                case 2: hipLaunchKernelGGL(k_align_band<2>, dim3(nk), dim3(64), 0, s, ap); break;
+                case 4: hipLaunchKernelGGL(k_align_band<4>, dim3(nk), dim3(64), 0, s, ap); break;
+                case 6: hipLaunchKernelGGL(k_align_band<6>, dim3(nk), dim3(64), 0, s, ap); break;
+                case 8: hipLaunchKernelGGL(k_align_band<8>, dim3(nk), dim3(64), 0, s, ap); break;
+                case 12: hipLaunchKernelGGL(k_align_band<12>, dim3(nk), dim3(64), 0, s, ap); break;
+                default: hipLaunchKernelGGL(k_align_band<16>, dim3(nk), dim3(64), 0, s, ap); break;
+            }
+            HIPCHK(c, hipGetLastError());
+        }
         HIPCHK(c, hipStreamSynchronize(s));       // (the direction buffer is reused by the next group)
+        if (t_dbg) {
+            const double now = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+            fprintf(stderr, "dagcon_align: group of %u pairs, %.1f MB of directions: %.2f ms (upload + kernels)\n", cnt, rows * 256.0 / 1e6, (now - t_grp) * 1e3);
+            t_grp = now;
+        }
         first += cnt;
     }
     HIPCHK(c, d2h(c, aln_len, dlen.p, (size_t)n * 4));
     HIPCHK(c, d2h(c, qaln, dqa.p, out_bytes));
     HIPCHK(c, d2h(c, taln, dta.p, out_bytes));
-    // the kernel fills each pair's room from the back (it walks the alignment from its end)
-    for (uint32_t a = 0; a < n; a++) {
-        const uint64_t cap = (uint64_t)q_len[a] + t_len[a], len = aln_len[a];
-        if (len > cap) return fail(c, DAGCON_ERR_INTERNAL, "pair %u: alignment longer than its room", a);
-        if (q_len[a] == 0 || t_len[a] == 0) continue;    // (written from the front)
-        memmove(qaln + out_off[a], qaln + out_off[a] + (cap - len), len);
-        memmove(taln + out_off[a], taln + out_off[a] + (cap - len), len);
-    }
+    for (uint32_t a = 0; a < n; a++)
+        if ((uint64_t)aln_len[a] > (uint64_t)q_len[a] + t_len[a]) return fail(c, DAGCON_ERR_INTERNAL, "pair %u: alignment longer than its room", a);
     return DAGCON_OK;
 }
 

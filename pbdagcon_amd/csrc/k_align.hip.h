@@ -11,23 +11,30 @@
 // j = i * tlen / qlen (the role of GuidedAlign's band around the SDP chain).  The tests hold a bit-exact
 // CPU twin of it.
 //
-// One wave per alignment.  A row of the band (<= 961 cells) lives in LDS; lane l owns C = ceil(B / 64)
-// consecutive cells.  The dependency on the cell to the left inside a row (deletions) is a running
-// minimum, S[k] = min_{k' <= k} (A[k'] - 5 k') + 5 k with A = min(diagonal, insertion), so a row is C
-// sequential steps per lane plus one wave-wide prefix minimum instead of B sequential steps.  Two bits
-// of direction per cell go to HBM as one coalesced 256-byte store per row; the walk back from
-// (qlen, tlen) reads them through LDS, 64 rows at a time.
+// One wave per alignment, the band of a row in REGISTERS: B = 2 W + 1 cells right-aligned on 64 lanes x C
+// cells (C = 2 .. 16, one kernel instance per C), lane l owning cells l C .. l C + C - 1 with their previous-row
+// scores and their target characters.  When the band's centre moves on by one column, scores and characters
+// move one cell to the left (C register moves and two DPP wave shifts; the entering character comes out of a
+// 64-character prefetch register), so a cell's diagonal and upper neighbours are always the cell to its left
+// and itself: no LDS, no barrier in the row loop.  The dependency on the cell to the left inside a row
+// (deletions) is a running minimum, S[k] = min_{k' <= k} (A[k'] - 5 k') + 5 k with A = min(diagonal,
+// insertion): C sequential steps per lane plus one DPP prefix minimum over the lanes.  Two bits of direction
+// per cell go to HBM as one coalesced 256-byte store per row.  The walk back from (qlen, tlen) runs on scalar
+// registers, rows of directions staged through LDS 16 at a time, and leaves one code per step; the
+// characters are then filled in 64 steps at a time (ballot prefix counts give every step its i and j).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #define DG_AL_MATCH (-5)
 #define DG_AL_MISMATCH 6
 #define DG_AL_INS 4
 #define DG_AL_DEL 5
-#define DG_AL_INF (1 << 28)
+#define DG_AL_BIG (1 << 28)      // unreachable: every score >= DG_AL_LIM is (reachable scores stay below 2^23)
+#define DG_AL_LIM (1 << 27)
 #define DG_AL_MAXW 480u
-#define DG_AL_ROWS 64            // rows of directions staged in LDS during the walk back
+#define DG_AL_ROWS 16            // rows of directions staged in LDS during the walk back
 
 __host__ __device__ inline uint32_t dg_isqrt64(uint64_t x) {
     uint64_t r = 0, b = 1ull << 62;
@@ -44,138 +51,249 @@ __host__ __device__ inline uint32_t dg_align_halfwidth(uint32_t qlen, uint32_t t
     uint32_t w = 32u + 4u * dg_isqrt64((15ull * L + 99ull) / 100ull);
     return w > DG_AL_MAXW ? DG_AL_MAXW : w;
 }
+// cells per lane a pair needs, rounded up to a kernel instance (2, 4, 6, 8, 12, 16)
+__host__ __device__ inline uint32_t dg_align_cells(uint32_t qlen, uint32_t tlen) {
+    const uint32_t c = (2u * dg_align_halfwidth(qlen, tlen) + 1u + 63u) / 64u;
+    return c <= 2 ? 2u : c <= 4 ? 4u : c <= 6 ? 6u : c <= 8 ? 8u : c <= 12 ? 12u : 16u;
+}
+// rows of 64 words a pair takes in the direction buffer: its q_len + 1 rows, then one code per step of the walk
+__host__ __device__ inline uint64_t dg_align_rows(uint32_t qlen, uint32_t tlen) {
+    return (uint64_t)qlen + 1ull + ((uint64_t)qlen + tlen + 255ull) / 256ull + 1ull;
+}
 
 struct DgAlignParams {
     const uint8_t *q, *t;          // sequence blobs
     const uint64_t *q_off, *t_off;
     const uint32_t *q_len, *t_len;
     const uint64_t *out_off;       // per alignment: room for q_len + t_len columns in qaln / taln
-    uint8_t *qaln, *taln;          // written from the BACK of each alignment's room
+    uint8_t *qaln, *taln;          // written from the front of each alignment's room
     uint32_t *aln_len;
     uint32_t *dirs;                // direction words: 64 per row
-    const uint64_t *dir_off;       // per alignment, in rows
-    uint32_t first, n;             // alignments [first, first + n) of the arrays
+    const uint64_t *dir_off;       // per alignment, in rows (dg_align_rows of them)
+    const uint32_t *idx;           // the alignments of this launch
+    uint32_t n;
 };
 
-__global__ __launch_bounds__(64) void k_align_banded(DgAlignParams p) {
-    __shared__ int32_t s_row[2][1024];
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dg_al_dpp(int old, int src) {
+    return __builtin_amdgcn_update_dpp(old, src, CTRL, ROW_MASK, 0xf, false);
+}
+// s_waitcnt vmcnt(0) where a (rare) block has loaded from HBM: the compiler then knows that nothing is pending
+// when the row loop goes on, and does not make every row wait for the previous row's direction store
+#define DG_AL_WAIT_LOADS() __builtin_amdgcn_s_waitcnt(0x0F70)
+#define DG_DPP_ROW_SHR(n) (0x110 + (n))
+#define DG_DPP_WAVE_SHL1 0x130     // lane l reads lane l + 1
+#define DG_DPP_WAVE_SHR1 0x138     // lane l reads lane l - 1
+#define DG_DPP_BCAST15 0x142
+#define DG_DPP_BCAST31 0x143
+
+template <int C>
+__global__ __launch_bounds__(64) void k_align_band(DgAlignParams p) {
     __shared__ uint32_t s_dir[DG_AL_ROWS * 64];
-    const uint32_t a = p.first + blockIdx.x;
+    // the characters the row loop consumes one at a time (q[i - 1]; the t character that enters the band on its
+    // right) come out of two 128-character LDS windows, refilled 64 at a time: a global load inside the row loop
+    // would make every row wait for the previous row's direction store (gfx950 counts stores in vmcnt)
+    __shared__ uint8_t s_qw[128], s_tw[128];
+    const uint32_t a = p.idx[blockIdx.x];
     const int lane = threadIdx.x;
     const uint32_t n = p.q_len[a], m = p.t_len[a];
     const uint8_t *q = p.q + p.q_off[a], *t = p.t + p.t_off[a];
     uint8_t *qo = p.qaln + p.out_off[a], *to = p.taln + p.out_off[a];
-    const uint32_t cap = n + m;
     if (n == 0 || m == 0) {
         // all gaps, in order: query columns first
         for (uint32_t i = lane; i < n; i += 64) { qo[i] = q[i]; to[i] = '-'; }
         for (uint32_t j = lane; j < m; j += 64) { qo[n + j] = '-'; to[n + j] = t[j]; }
-        if (lane == 0) p.aln_len[a] = cap;
+        if (lane == 0) p.aln_len[a] = n + m;
         return;
     }
-    const uint32_t W = dg_align_halfwidth(n, m), B = 2u * W + 1u;
-    const uint32_t C = (B + 63u) / 64u;                     // cells per lane (<= 16)
+    const int W = (int)dg_align_halfwidth(n, m), B = 2 * W + 1;
+    const int off = 64 * C - B;                             // dead cells in front of the band (host: B <= 64 C)
     uint32_t *dirs = p.dirs + p.dir_off[a] * 64ull;
-    const uint32_t k0 = (uint32_t)lane * C;
-    for (uint32_t k = lane; k < 1024; k += 64) { s_row[0][k] = DG_AL_INF; s_row[1][k] = DG_AL_INF; }
-    __syncthreads();
-    int64_t cp = 0;
-    for (uint32_t i = 0; i <= n; i++) {
-        const int64_t ci = (int64_t)((uint64_t)i * m / n);
-        const int32_t *prev = s_row[(i & 1u) ^ 1u];
-        int32_t *cur = s_row[i & 1u];
-        const int shift = (int)(ci - cp);
-        const uint8_t qc = i ? q[i - 1] : 0;
-        // A = min(diagonal, insertion) for the lane's cells, then the running minimum over the row
-        int32_t A[16];
-        uint32_t dbits = 0;                                 // bit k: 1 = insertion wins over the diagonal
-        int32_t run = DG_AL_INF;                            // min over this lane's cells so far of (A[k] - DEL k)
-        int32_t X[16];
+    uint8_t *path = reinterpret_cast<uint8_t *>(dirs + ((uint64_t)n + 1ull) * 64ull);   // one code per step of the walk
+
+    // ---- forward: row i holds columns j = c_i - W + k, k = 0 .. B - 1, c_i = i m / n ----
+    int P[C], T[C];
+    int jl = -W - off + lane * C;                           // column of the lane's first cell
 #pragma unroll
-        for (int c = 0; c < 16; c++) {
-            A[c] = DG_AL_INF; X[c] = DG_AL_INF;
-            if ((uint32_t)c < C) {
-                const uint32_t k = k0 + (uint32_t)c;
-                const int64_t j = ci - (int64_t)W + (int64_t)k;
-                if (k < B && j >= 0 && j <= (int64_t)m) {
-                    int32_t best = DG_AL_INF;
-                    if (i == 0 && j == 0) best = 0;
-                    if (i > 0) {
-                        const int64_t kd = (int64_t)k + shift - 1, ku = kd + 1;
-                        if (j > 0 && kd >= 0 && kd < (int64_t)B) {
-                            const int32_t pv = prev[kd];
-                            if (pv < DG_AL_INF) best = pv + (qc == t[j - 1] ? DG_AL_MATCH : DG_AL_MISMATCH);
-                        }
-                        if (ku >= 0 && ku < (int64_t)B) {
-                            const int32_t pv = prev[ku];
-                            if (pv < DG_AL_INF && pv + DG_AL_INS < best) { best = pv + DG_AL_INS; dbits |= 1u << c; }
-                        }
+    for (int c = 0; c < C; c++) {
+        const int j = jl + c;
+        P[c] = DG_AL_BIG;
+        T[c] = (j >= 1 && j <= (int)m) ? (int)t[j - 1] : 0;
+    }
+    // window r -> slot r & 127: s_tw holds t[tw0 + r] (tw0 = W: the first character to enter), s_qw holds q[r]
+    int tw0 = W;
+    uint32_t tr = 0;                                        // characters of the window consumed so far
+    for (int x = lane; x < 128; x += 64) {
+        s_tw[x] = (uint32_t)(tw0 + x) < m ? t[tw0 + x] : (uint8_t)0;
+        s_qw[x] = (uint32_t)x < n ? q[x] : (uint8_t)0;
+    }
+    DG_AL_WAIT_LOADS();
+    uint32_t num = 0;                                       // i m = c_i n + num
+    int ci = 0;
+    int tcur = (int)s_tw[0];                                // the next character to enter
+    int qc = -1, qcn = (int)s_qw[0];                        // q[i - 1] of this row, of the next
+    auto row = [&](const uint32_t i, auto first_row) {
+        constexpr bool FIRST = decltype(first_row)::value;
+        if constexpr (!FIRST) {
+            num += m;
+            uint32_t shift = 0;
+            while (num >= n) { num -= n; shift++; }
+            if (shift > (uint32_t)B) {
+                // the band jumps by more than its width (tlen >> qlen): nothing of the previous row is in reach of this one
+                ci += (int)shift; jl += (int)shift;
+#pragma unroll
+                for (int c = 0; c < C; c++) {
+                    const int j = jl + c;
+                    P[c] = DG_AL_BIG;
+                    T[c] = (j >= 1 && j <= (int)m) ? (int)t[j - 1] : 0;
+                }
+                tw0 = ci + W; tr = 0;
+                for (int x = lane; x < 128; x += 64) s_tw[x] = (uint32_t)(tw0 + x) < m ? t[tw0 + x] : (uint8_t)0;
+                DG_AL_WAIT_LOADS();
+                tcur = (int)s_tw[0];
+            } else {
+                for (uint32_t s = 0; s < shift; s++) {
+                    ci++; jl++;
+                    const int newc = tcur;                                          // t[c_i + W - 1] (0 past the end of t)
+                    tr++;
+                    if ((tr & 63u) == 0 && tr >= 64u) {                             // the half behind is finished with
+                        const uint32_t r = tr + 64u + (uint32_t)lane;
+                        s_tw[r & 127u] = (uint32_t)tw0 + r < m ? t[(uint32_t)tw0 + r] : (uint8_t)0;
+                        DG_AL_WAIT_LOADS();
                     }
-                    A[c] = best;
-                    if (best < DG_AL_INF) X[c] = best - DG_AL_DEL * (int32_t)k;
+                    tcur = (int)s_tw[tr & 127u];
+                    int pin = dg_al_dpp<DG_DPP_WAVE_SHL1, 0xf>(DG_AL_BIG, P[0]);
+                    int tin = dg_al_dpp<DG_DPP_WAVE_SHL1, 0xf>(0, T[0]);
+                    if (lane == 63) { pin = DG_AL_BIG; tin = newc; }
+#pragma unroll
+                    for (int c = 0; c + 1 < C; c++) { P[c] = P[c + 1]; T[c] = T[c + 1]; }
+                    P[C - 1] = pin; T[C - 1] = tin;
                 }
             }
+            qc = qcn;
+            if ((i & 63u) == 0 && i >= 64u) {                                       // q[i .. i + 63] went out of use
+                const uint32_t r = i + 64u + (uint32_t)lane;
+                s_qw[r & 127u] = r < n ? q[r] : (uint8_t)0;
+                DG_AL_WAIT_LOADS();
+            }
+            qcn = (int)s_qw[i & 127u];                                              // q[i]: the next row's
         }
-        // exclusive prefix minimum of the lanes' minima
+        // A = min(diagonal, insertion) of the lane's cells
+        const int left = dg_al_dpp<DG_DPP_WAVE_SHR1, 0xf>(DG_AL_BIG, P[C - 1]);     // the lane in front: its last cell
+        int A[C];
+        uint32_t dbits = 0;                                 // bit c: insertion wins over the diagonal
+        int lm = DG_AL_BIG;
+        const int kb = lane * C;                            // (scores go through X = A - 5 k: any common origin of k does)
 #pragma unroll
-        for (int c = 0; c < 16; c++) if ((uint32_t)c < C && X[c] < run) run = X[c];
-        int32_t incl = run;
-        for (int o = 1; o < 64; o <<= 1) {
-            const int32_t up = __shfl_up(incl, o);
-            if (lane >= o && up < incl) incl = up;
+        for (int c = 0; c < C; c++) {
+            const int j = jl + c;
+            const bool valid = (uint32_t)j <= m && kb + c >= off;
+            int best;
+            if constexpr (FIRST) best = j == 0 ? 0 : DG_AL_BIG;
+            else {
+                const int dg = (c == 0 ? left : P[c - 1]) + (T[c] == qc ? DG_AL_MATCH : DG_AL_MISMATCH);
+                const int up = P[c] + DG_AL_INS;
+                const bool ins = up < dg;
+                best = ins ? up : dg;
+                dbits |= ins ? 1u << c : 0u;
+            }
+            best = valid ? best : DG_AL_BIG;
+            A[c] = best;
+            const int x = best - DG_AL_DEL * (kb + c);
+            lm = x < lm ? x : lm;
         }
-        int32_t P = __shfl_up(incl, 1);
-        if (lane == 0) P = DG_AL_INF;
+        // exclusive prefix minimum over the lanes in front
+        int incl = lm, v;
+        v = dg_al_dpp<DG_DPP_ROW_SHR(1), 0xf>(DG_AL_BIG, incl); incl = v < incl ? v : incl;
+        v = dg_al_dpp<DG_DPP_ROW_SHR(2), 0xf>(DG_AL_BIG, incl); incl = v < incl ? v : incl;
+        v = dg_al_dpp<DG_DPP_ROW_SHR(4), 0xf>(DG_AL_BIG, incl); incl = v < incl ? v : incl;
+        v = dg_al_dpp<DG_DPP_ROW_SHR(8), 0xf>(DG_AL_BIG, incl); incl = v < incl ? v : incl;
+        v = dg_al_dpp<DG_DPP_BCAST15, 0xa>(DG_AL_BIG, incl); incl = v < incl ? v : incl;
+        v = dg_al_dpp<DG_DPP_BCAST31, 0xc>(DG_AL_BIG, incl); incl = v < incl ? v : incl;
+        int pm = dg_al_dpp<DG_DPP_WAVE_SHR1, 0xf>(DG_AL_BIG, incl);
         uint32_t word = 0;
 #pragma unroll
-        for (int c = 0; c < 16; c++) {
-            if ((uint32_t)c < C) {
-                const uint32_t k = k0 + (uint32_t)c;
-                const int64_t j = ci - (int64_t)W + (int64_t)k;
-                const bool valid = k < B && j >= 0 && j <= (int64_t)m;
-                uint32_t d = 3u;
-                int32_t S = DG_AL_INF;
-                if (valid) {
-                    // deletion (left) wins only when strictly better than diagonal / insertion
-                    if (j > 0 && P < X[c]) { S = P + DG_AL_DEL * (int32_t)k; d = 2u; }
-                    else if (A[c] < DG_AL_INF) { S = A[c]; d = (dbits >> c) & 1u; }
-                    if (i == 0 && j == 0) d = 3u;
-                    if (X[c] < P) P = X[c];
-                }
-                if (k < 1024u) cur[k] = S;
-                word |= d << (2 * c);
-            }
+        for (int c = 0; c < C; c++) {
+            const int j = jl + c;
+            const bool valid = (uint32_t)j <= m && kb + c >= off;
+            const int x = A[c] - DG_AL_DEL * (kb + c);
+            // deletion (left) wins only when strictly better than diagonal / insertion
+            const bool del = j > 0 && pm < x;
+            int sc = del ? pm + DG_AL_DEL * (kb + c) : A[c];
+            const uint32_t d = del ? 2u : (dbits >> c) & 1u;
+            pm = x < pm ? x : pm;
+            P[c] = valid ? sc : DG_AL_BIG;
+            word |= d << (2 * c);
         }
         dirs[(uint64_t)i * 64ull + (uint64_t)lane] = word;
-        cp = ci;
-        __syncthreads();
+    };
+    row(0u, std::true_type{});
+    for (uint32_t i = 1; i <= n; i++) row(i, std::false_type{});
+    // (n, m) is cell k = W of the last row
+    const int kend = W + off;
+    int fin = DG_AL_BIG;
+#pragma unroll
+    for (int c = 0; c < C; c++) if (kend % C == c) fin = P[c];
+    fin = __builtin_amdgcn_readlane(fin, kend / C);
+    if (fin >= DG_AL_LIM) {                                 // the band does not connect (0, 0) with (n, m)
+        if (lane == 0) p.aln_len[a] = 0;
+        return;
     }
-    // ---- walk back from (n, m): directions through LDS, DG_AL_ROWS rows at a time ----
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+
+    // ---- walk back from (n, m): uniform, directions through LDS, one code per step ----
     uint32_t i = n, j = m, len = 0;
-    __shared__ uint32_t s_state[3];
+    int wci = (int)m;                                       // c_i of the row the walk is on
+    uint32_t wnum = 0;
+    int r0 = (int)n + 1;                                    // rows [r0, ..] are staged
+    int codes = 0;
+    const uint32_t cap = n + m;
+    bool bad = false;
     while (i > 0 || j > 0) {
-        const uint32_t r1 = i, r0 = i >= DG_AL_ROWS - 1 ? i - (DG_AL_ROWS - 1) : 0u;     // rows [r0, r1]
-        for (uint32_t x = lane; x < (r1 - r0 + 1u) * 64u; x += 64) s_dir[x] = dirs[(uint64_t)r0 * 64ull + x];
-        __syncthreads();
-        if (lane == 0) {
-            while ((i > 0 || j > 0) && i >= r0) {
-                const int64_t ci = (int64_t)((uint64_t)i * m / n);
-                const uint32_t k = (uint32_t)((int64_t)j - (ci - (int64_t)W));
-                const uint32_t d = (s_dir[(i - r0) * 64u + k / C] >> (2u * (k % C))) & 3u;
-                uint8_t qb, tb;
-                if (d == 0u) { qb = q[--i]; tb = t[--j]; }
-                else if (d == 1u) { qb = q[--i]; tb = '-'; }
-                else if (d == 2u) { qb = '-'; tb = t[--j]; }
-                else { i = 0; j = 0; break; }               // cannot happen: (0, 0) is inside the band
-                len++;
-                qo[cap - len] = qb; to[cap - len] = tb;
-                if (i < r0) break;
-            }
-            s_state[0] = i; s_state[1] = j; s_state[2] = len;
+        if ((int)i < r0) {
+            __syncthreads();
+            r0 = (int)i >= DG_AL_ROWS - 1 ? (int)i - (DG_AL_ROWS - 1) : 0;
+            for (uint32_t x = lane; x < ((uint32_t)((int)i - r0) + 1u) * 64u; x += 64) s_dir[x] = dirs[(uint64_t)r0 * 64ull + x];
+            __syncthreads();
         }
-        __syncthreads();
-        i = s_state[0]; j = s_state[1]; len = s_state[2];
-        __syncthreads();
+        const int k = (int)j - (wci - W) + off;
+        if (k < off || k >= 64 * C || len >= cap) { bad = true; break; }     // cannot happen on a connected band
+        const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_dir[((int)i - r0) * 64 + k / C]);
+        const uint32_t d = (w >> (2 * (k % C))) & 3u;
+        if (d == 3u) { bad = true; break; }
+        codes = (uint32_t)lane == (len & 63u) ? (int)d : codes;
+        len++;
+        if ((len & 63u) == 0) path[len - 64u + (uint32_t)lane] = (uint8_t)codes;
+        if (d != 2u) {
+            if (i == 0) { bad = true; break; }
+            i--;
+            while (wnum < m) { wnum += n; wci--; }
+            wnum -= m;
+        }
+        if (d != 1u) {
+            if (j == 0) { bad = true; break; }
+            j--;
+        }
+    }
+    if (bad) { if (lane == 0) p.aln_len[a] = 0; return; }
+    if ((uint32_t)lane < (len & 63u)) path[(len & ~63u) + (uint32_t)lane] = (uint8_t)codes;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __syncthreads();
+    // ---- the characters, 64 steps at a time: step s consumed q[i_s - 1] and / or t[j_s - 1] ----
+    uint32_t iq = n, jt = m;
+    for (uint32_t s0 = 0; s0 < len; s0 += 64) {
+        const uint32_t s = s0 + (uint32_t)lane;
+        const bool on = s < len;
+        const uint32_t d = on ? path[s] : 3u;
+        const bool uq = on && d != 2u, ut = on && d != 1u;
+        const unsigned long long mq = __ballot(uq), mt = __ballot(ut);
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        const uint32_t myi = iq - (uint32_t)__popcll(mq & lt), myj = jt - (uint32_t)__popcll(mt & lt);
+        if (on) {
+            qo[len - 1u - s] = uq ? q[myi - 1u] : (uint8_t)'-';
+            to[len - 1u - s] = ut ? t[myj - 1u] : (uint8_t)'-';
+        }
+        iq -= (uint32_t)__popcll(mq); jt -= (uint32_t)__popcll(mt);
     }
     if (lane == 0) p.aln_len[a] = len;
 }

@@ -738,8 +738,9 @@ def _mutate(rng, t, sub=0.03, ins=0.08, dele=0.05):
 def test_align_kat_and_twin(gpu_ctx_factory, monkeypatch):
     """dagcon_align against its CPU twin (oracle.banded_align), bit for bit: the reference's one
     known-answer test (test/cpp/SimpleAlignerTest.cpp:8-21), empty and one-base sequences, pairs of
-    very different lengths (band edges), pairs of several thousand bases (band narrower than the
-    matrix, directions staged through LDS in many rounds), and several launch groups."""
+    very different lengths (band edges), pairs of several thousand to a hundred thousand bases (band
+    narrower than the matrix, every kernel instance, directions staged through LDS in many rounds), a
+    band that does not connect the corners, and several launch groups."""
     import json
     import os
     k = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kat_graph.json")))["simple_aligner"]
@@ -758,7 +759,18 @@ def test_align_kat_and_twin(gpu_ctx_factory, monkeypatch):
         t = bytes(b"ACGT"[j] for j in rng.integers(0, 4, n))
         pairs.append((_mutate(rng, t), t))
         pairs.append((_mutate(rng, t, ins=0.2), t[: n // 2]))       # the band does not reach the corner cleanly
+    # every kernel instance (2 .. 16 cells per lane: the band is 2 W + 1 cells on 64 lanes)
+    for n in (20000, 45000, 110000):
+        t = bytes(b"ACGT"[j] for j in rng.integers(0, 4, n))
+        pairs.append((_mutate(rng, t), t))
+    # a target far longer than the query: the band jumps more than its width from row to row and never
+    # connects the corners (the twin then returns nothing: its walk stops at the unreachable corner)
+    t = bytes(b"ACGT"[j] for j in rng.integers(0, 4, 5000))
+    pairs.append((t[:3], t))
+    pairs.append((t[:40], t[:3000]))
+    pairs.append((t, t[:40]))
     exp = [oracle.banded_align(q, t) for q, t in pairs]
+    assert exp[-3] == (b"", b"")
     assert ctx.align(pairs) == exp
     monkeypatch.setenv("DAGCON_ALIGN_ROWS", "5000")                 # several launch groups
     assert ctx.align(pairs) == exp
