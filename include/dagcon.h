@@ -207,6 +207,31 @@ int dagcon_align(dagcon_ctx *ctx, uint32_t n, const uint64_t *q_off, const uint3
                  uint32_t *aln_len);
 
 /*
+ * What main.cpp:117-145 does with -a, in one call: the records of a batch of targets as the .pre format carries
+ * them (Alignment.cpp:82-112: tstart is Alignment::start as parsePre leaves it, q / t the unaligned sequences) are
+ * re-aligned as by dagcon_align, start / end / strand handled as SimpleAligner.cpp:51-62 does (start = tstart,
+ * end = start + t_len; '-': start = tlen - end and both strings reverse-complemented; start += 1), then
+ * filtered, normalised, trimmed and threaded as by dagcon_consensus.  The aligned strings stay on the device.
+ * Same parity statement as dagcon_align.
+ */
+typedef struct dagcon_pre_batch {
+    uint32_t n_targets;
+    const uint32_t *tlen;        /* [n_targets] */
+    const uint64_t *rec_begin;   /* [n_targets + 1]: records of target g are rec_begin[g] .. rec_begin[g + 1] - 1 */
+    const uint32_t *tstart;      /* [n_rec] */
+    const char *strand;          /* [n_rec] '+' or '-' */
+    const uint64_t *q_off;       /* [n_rec] query sequence: q_blob[q_off .. + q_len) */
+    const uint32_t *q_len;
+    const uint64_t *t_off;       /* [n_rec] target sequence (in the read's orientation): t_blob[t_off .. + t_len) */
+    const uint32_t *t_len;
+    const char *q_blob;
+    uint64_t q_bytes;
+    const char *t_blob;
+    uint64_t t_bytes;
+} dagcon_pre_batch;
+int dagcon_consensus_pre(dagcon_ctx *ctx, const dagcon_pre_batch *batch, dagcon_results *results);
+
+/*
  * Debug / parity aid: adjacency of one target's graph as left by the last
  * dagcon_run (after mergeNodes), in list order.  Vertex ids are in backbone
  * position order: the inserted vertices whose _bbMap is p (in read, column

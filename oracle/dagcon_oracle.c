@@ -220,21 +220,27 @@ uint32_t og_align_halfwidth(uint32_t qlen, uint32_t tlen) {
     return w;
 }
 
+/* The band tried first: two of those.  The alignment found in it stands if its path keeps
+ * OG_AL_MARGIN cells away from both edges of the band on every row; else the pair is done again in the full band. */
+uint32_t og_align_halfwidth_first(uint32_t qlen, uint32_t tlen) {
+    const uint64_t L = qlen > tlen ? qlen : tlen;
+    uint32_t w = 32u + 2u * isqrt_u64((15ull * L + 99ull) / 100ull);
+    const uint32_t full = og_align_halfwidth(qlen, tlen);
+    return w > full ? full : w;
+}
+#define OG_AL_MARGIN 8
+
 #define OG_AL_MATCH (-5)
 #define OG_AL_MISMATCH 6
 #define OG_AL_INS 4
 #define OG_AL_DEL 5
 #define OG_AL_INF (1 << 28)
 
-size_t og_banded_align(const char *q, uint32_t n, const char *t, uint32_t m, char *qaln, char *taln) {
-    if (n == 0 || m == 0) {
-        size_t k = 0;
-        for (uint32_t i = 0; i < n; i++) { qaln[k] = q[i]; taln[k] = '-'; k++; }
-        for (uint32_t j = 0; j < m; j++) { qaln[k] = '-'; taln[k] = t[j]; k++; }
-        qaln[k] = taln[k] = 0;
-        return k;
-    }
-    const uint32_t W = og_align_halfwidth(n, m), B = 2 * W + 1;
+/* the global alignment inside the band of half-width W; *touched: its path came within OG_AL_MARGIN cells of an edge */
+static size_t og_banded_align_w(const char *q, uint32_t n, const char *t, uint32_t m, uint32_t W, char *qaln, char *taln,
+                                int *touched) {
+    const uint32_t B = 2 * W + 1;
+    *touched = 0;
     /* row i holds columns j = c_i - W + k, k = 0..B-1, c_i = i * m / n */
     int32_t *prev = (int32_t *)malloc(sizeof(int32_t) * B), *cur = (int32_t *)malloc(sizeof(int32_t) * B);
     uint8_t *dir = (uint8_t *)malloc((size_t)(n + 1) * B);
@@ -275,7 +281,9 @@ size_t og_banded_align(const char *q, uint32_t n, const char *t, uint32_t m, cha
     uint32_t i = n, j = m;
     while (i > 0 || j > 0) {
         const int64_t ci = (int64_t)((uint64_t)i * m / n);
-        const uint8_t d = dir[(size_t)i * B + (size_t)((int64_t)j - (ci - (int64_t)W))];
+        const int64_t kk = (int64_t)j - (ci - (int64_t)W);
+        if (kk < OG_AL_MARGIN || kk > (int64_t)B - 1 - OG_AL_MARGIN) *touched = 1;
+        const uint8_t d = dir[(size_t)i * B + (size_t)kk];
         if (d == 0) { rq[len] = q[--i]; rt[len] = t[--j]; }
         else if (d == 1) { rq[len] = q[--i]; rt[len] = '-'; }
         else if (d == 2) { rq[len] = '-'; rt[len] = t[--j]; }
@@ -285,6 +293,22 @@ size_t og_banded_align(const char *q, uint32_t n, const char *t, uint32_t m, cha
     for (size_t k = 0; k < len; k++) { qaln[k] = rq[len - 1 - k]; taln[k] = rt[len - 1 - k]; }
     qaln[len] = taln[len] = 0;
     free(prev); free(cur); free(dir); free(rq); free(rt);
+    return len;
+}
+
+size_t og_banded_align(const char *q, uint32_t n, const char *t, uint32_t m, char *qaln, char *taln) {
+    if (n == 0 || m == 0) {
+        size_t k = 0;
+        for (uint32_t i = 0; i < n; i++) { qaln[k] = q[i]; taln[k] = '-'; k++; }
+        for (uint32_t j = 0; j < m; j++) { qaln[k] = '-'; taln[k] = t[j]; k++; }
+        qaln[k] = taln[k] = 0;
+        return k;
+    }
+    const uint32_t w1 = og_align_halfwidth_first(n, m), w2 = og_align_halfwidth(n, m);
+    int touched = 0;
+    size_t len = og_banded_align_w(q, n, t, m, w1, qaln, taln, &touched);
+    /* near an edge, or no path at all inside the narrow band: the full band decides */
+    if (w1 < w2 && (touched || len == 0)) len = og_banded_align_w(q, n, t, m, w2, qaln, taln, &touched);
     return len;
 }
 

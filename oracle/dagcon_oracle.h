@@ -65,9 +65,12 @@ int og_parse_pre(const char *line, size_t len, og_parsed *out, uint32_t *end_out
  * reproduces: a global alignment that minimises blasr's distance score (SimpleAligner.cpp:10-23:
  * match -5, mismatch +6 from SMRTDistanceMatrix, insertion 4, deletion 5), ties resolved
  * diagonal first, then insertion (gap in the target), then deletion, inside a band of half-width
- * og_align_halfwidth(qlen, tlen) around the length-scaled diagonal j = i * tlen / qlen.
+ * og_align_halfwidth(qlen, tlen) around the length-scaled diagonal j = i * tlen / qlen.  The band of
+ * og_align_halfwidth_first() is tried first: what it finds stands when the path keeps 8 cells away from its
+ * edges, else the full band decides.
  * Outputs (capacity qlen + tlen + 1 each) get the aligned strings; returns their length. */
 uint32_t og_align_halfwidth(uint32_t qlen, uint32_t tlen);
+uint32_t og_align_halfwidth_first(uint32_t qlen, uint32_t tlen);   /* the band tried first (see og_banded_align) */
 size_t og_banded_align(const char *q, uint32_t qlen, const char *t, uint32_t tlen, char *qaln, char *taln);
 /* SimpleAligner.cpp:51-62: what align() does to start / end / strings once the aligner has
  * produced (queryStr, targetStr, GenomicTBegin = 0, GenomicTEnd = tlen of the record's tstr).

@@ -30,6 +30,7 @@ EXPORTS = [
     "dagcon_last_error", "dagcon_consensus", "dagcon_upload", "dagcon_run", "dagcon_sync",
     "dagcon_fetch", "dagcon_get_timings", "dagcon_normalize", "dagcon_debug_graph",
     "dagcon_debug_counters", "dagcon_host_alloc", "dagcon_host_free", "dagcon_align",
+    "dagcon_consensus_pre",
 ]
 ABI_VERSION = 2
 
@@ -51,6 +52,13 @@ class Batch(C.Structure):
                 ("aln_start", C.c_void_p), ("aln_off", C.c_void_p), ("aln_len", C.c_void_p),
                 ("qstr", C.c_void_p), ("tstr", C.c_void_p), ("blob_bytes", C.c_uint64),
                 ("backbone", C.c_void_p), ("backbone_off", C.c_void_p)]
+
+
+class PreBatch(C.Structure):
+    _fields_ = [("n_targets", C.c_uint32), ("tlen", C.c_void_p), ("rec_begin", C.c_void_p),
+                ("tstart", C.c_void_p), ("strand", C.c_void_p), ("q_off", C.c_void_p), ("q_len", C.c_void_p),
+                ("t_off", C.c_void_p), ("t_len", C.c_void_p), ("q_blob", C.c_void_p), ("q_bytes", C.c_uint64),
+                ("t_blob", C.c_void_p), ("t_bytes", C.c_uint64)]
 
 
 class Results(C.Structure):
@@ -342,6 +350,32 @@ class Context:
                                       qa.ctypes.data, ta.ctypes.data, ln.ctypes.data))
         return [(qa[int(oo[a]):int(oo[a]) + int(ln[a])].tobytes(), ta[int(oo[a]):int(oo[a]) + int(ln[a])].tobytes())
                 for a in range(n)]
+
+    def consensus_pre(self, targets, strict=True):
+        """targets = [(tlen, [(tstart, strand, qseq, tseq)])]: .pre records per target (Alignment.cpp:82-112)
+        -> per target [(range0, range1, seq_bytes)] (dagcon_consensus_pre: main.cpp:117-145 with -a)."""
+        recs = [r for _, rs in targets for r in rs]
+        n = len(recs)
+        tlen = np.array([t for t, _ in targets], dtype=np.uint32)
+        begin = np.zeros(len(targets) + 1, np.uint64)
+        begin[1:] = np.cumsum([len(rs) for _, rs in targets], dtype=np.uint64)
+        ts = np.array([r[0] for r in recs] or [0], dtype=np.uint32)
+        strand = np.frombuffer(b"".join(r[1] for r in recs) or b"+", dtype=np.uint8)
+        ql = np.array([len(r[2]) for r in recs] or [0], dtype=np.uint32)
+        tl = np.array([len(r[3]) for r in recs] or [0], dtype=np.uint32)
+        qo, to = np.zeros(max(n, 1), np.uint64), np.zeros(max(n, 1), np.uint64)
+        qo[1:] = np.cumsum(ql[:-1], dtype=np.uint64)
+        to[1:] = np.cumsum(tl[:-1], dtype=np.uint64)
+        qb = np.frombuffer(b"".join(r[2] for r in recs) or b"\0", dtype=np.uint8)
+        tb = np.frombuffer(b"".join(r[3] for r in recs) or b"\0", dtype=np.uint8)
+        pb = PreBatch(len(targets), tlen.ctypes.data, begin.ctypes.data, ts.ctypes.data, strand.ctypes.data,
+                      qo.ctypes.data, ql.ctypes.data, to.ctypes.data, tl.ctypes.data, qb.ctypes.data,
+                      int(ql.sum()) if n else 0, tb.ctypes.data, int(tl.sum()) if n else 0)
+        r = Results()
+        self.L.dagcon_consensus_pre.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        self._chk(self.L.dagcon_consensus_pre(self.h, C.byref(pb), C.byref(r)))
+        self._status(r, strict)
+        return _results_to_py(r)
 
     def debug_counters(self):
         a = (C.c_ulonglong * 16)()

@@ -66,7 +66,7 @@ struct Ctx {
     DevBuf d_matA, d_matD, d_matC, d_cov, d_gcount, d_gbase, d_bid;
     DevBuf d_nodes, d_best, d_queue, d_score, d_cns_tmp, d_bp_tt;
     DevBuf d_pool, d_stk, d_cuts, d_cuts_bp, d_bp_stat, d_bp_len, d_nextcut, d_tile_list, d_rd, d_pro_state, d_sh_cnt, d_seg_done, d_wl_first, d_queue0, d_bp_end, d_bp_ab, d_defer, d_cns_tmp0;
-    DevBuf d_al[13];                                // dagcon_align: blobs, offsets, outputs, directions, launch order
+    DevBuf d_al[14];                                // dagcon_align: blobs, offsets, outputs, directions, launch order, widths
     DevBuf d_cns, d_cns_off, d_cns_len, d_seg_first, d_n_seg, d_seg_r0, d_seg_r1, d_st;
 
     uint64_t norm_cap = 0, node_cap = 0, pool_cap = 0, cns_cap = 0, seg_cap = 0;
@@ -118,7 +118,13 @@ int ensure(Ctx *c, DevBuf &b, size_t bytes) {
     if (b.cap >= bytes) return DAGCON_OK;
     if (b.p) { (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
     size_t want = bytes + bytes / 16 + 256;
+    const bool dbg = getenv("DAGCON_ALLOC_TIMING") != nullptr;
+    const double t0 = dbg ? std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() : 0;
     hipError_t e = hipMalloc(&b.p, want);
+    if (dbg) {
+        const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - t0;
+        if (dt > 0.005) fprintf(stderr, "dagcon: hipMalloc(%.1f MB) took %.1f ms\n", want / 1e6, dt * 1e3);
+    }
     if (e != hipSuccess) {
         b.p = nullptr;
         return fail(c, DAGCON_ERR_WORKSPACE, "hipMalloc(%zu bytes) failed: %s", want, hipGetErrorString(e));
@@ -404,14 +410,15 @@ void dagcon_destroy(dagcon_ctx *ctx) {
     delete c;
 }
 
-int dagcon_upload(dagcon_ctx *ctx, const dagcon_batch *b) {
+// dev_q / dev_t: the blobs are on the device already (dagcon_consensus_pre: the aligner's output), b->qstr / tstr unused
+static int upload_impl(dagcon_ctx *ctx, const dagcon_batch *b, const void *dev_q, const void *dev_t) {
     if (!ctx || !b) return DAGCON_ERR_INVALID_ARG;
     Ctx *c = reinterpret_cast<Ctx *>(ctx);
     c->uploaded = c->ran = c->fetched = false;
     const uint32_t T = b->n_targets;
     if (T && (!b->tlen || !b->aln_begin)) return fail(c, DAGCON_ERR_INVALID_ARG, "tlen/aln_begin is NULL");
     const uint64_t A_all = T ? b->aln_begin[T] : 0;
-    if (A_all && (!b->aln_start || !b->aln_off || !b->aln_len || !b->qstr || !b->tstr))
+    if (A_all && (!b->aln_start || !b->aln_off || !b->aln_len || ((!b->qstr || !b->tstr) && !(dev_q && dev_t))))
         return fail(c, DAGCON_ERR_INVALID_ARG, "alignment arrays are NULL");
     if (b->backbone && !b->backbone_off) return fail(c, DAGCON_ERR_INVALID_ARG, "backbone_off is NULL");
     HIPCHK(c, hipSetDevice(c->device));
@@ -560,8 +567,8 @@ int dagcon_upload(dagcon_ctx *ctx, const dagcon_batch *b) {
     ENSURE(c, c->d_q, b->blob_bytes);
     ENSURE(c, c->d_t, b->blob_bytes);
     if (b->blob_bytes) {
-        HIPCHK(c, hipMemcpyAsync(c->d_q.p, b->qstr, b->blob_bytes, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipMemcpyAsync(c->d_t.p, b->tstr, b->blob_bytes, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->d_q.p, dev_q ? dev_q : b->qstr, b->blob_bytes, dev_q ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->d_t.p, dev_t ? dev_t : b->tstr, b->blob_bytes, dev_t ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
     }
     if (c->have_bb) {
         ENSURE(c, c->d_bb, bb_bytes);
@@ -619,6 +626,8 @@ int dagcon_upload(dagcon_ctx *ctx, const dagcon_batch *b) {
     c->tm.reruns = 0;
     return DAGCON_OK;
 }
+
+int dagcon_upload(dagcon_ctx *ctx, const dagcon_batch *b) { return upload_impl(ctx, b, nullptr, nullptr); }
 
 int dagcon_run(dagcon_ctx *ctx) {
     if (!ctx) return DAGCON_ERR_INVALID_ARG;
@@ -878,15 +887,10 @@ int dagcon_normalize(dagcon_ctx *ctx, uint32_t n, const uint32_t *aln_start, con
     return r;
 }
 
-int dagcon_align(dagcon_ctx *ctx, uint32_t n, const uint64_t *q_off, const uint32_t *q_len,
-                 const uint64_t *t_off, const uint32_t *t_len, const char *q_blob, uint64_t q_bytes,
-                 const char *t_blob, uint64_t t_bytes, const uint64_t *out_off, char *qaln, char *taln,
-                 uint32_t *aln_len) {
-    if (!ctx) return DAGCON_ERR_INVALID_ARG;
-    Ctx *c = reinterpret_cast<Ctx *>(ctx);
-    if (n == 0) return DAGCON_OK;
-    if (!q_off || !q_len || !t_off || !t_len || !q_blob || !t_blob || !out_off || !qaln || !taln || !aln_len)
-        return fail(c, DAGCON_ERR_INVALID_ARG, "NULL argument");
+// the -a stage on the device: aligned strings left in c->d_al[7] / [8] at out_off[a], their lengths in aln_len (host)
+static int align_device(Ctx *c, uint32_t n, const uint64_t *q_off, const uint32_t *q_len,
+                        const uint64_t *t_off, const uint32_t *t_len, const char *q_blob, uint64_t q_bytes,
+                        const char *t_blob, uint64_t t_bytes, const uint64_t *out_off, uint32_t *aln_len, uint64_t *out_bytes_ret) {
     HIPCHK(c, hipSetDevice(c->device));
     uint64_t out_bytes = 0;
     std::vector<uint64_t> dir_off(n);
@@ -910,83 +914,172 @@ int dagcon_align(dagcon_ctx *ctx, uint32_t n, const uint64_t *q_off, const uint3
     HIPCHK(c, hipMemcpyAsync(dql.p, q_len, (size_t)n * 4, hipMemcpyHostToDevice, s));
     HIPCHK(c, hipMemcpyAsync(dtl.p, t_len, (size_t)n * 4, hipMemcpyHostToDevice, s));
     HIPCHK(c, hipMemcpyAsync(doo.p, out_off, (size_t)n * 8, hipMemcpyHostToDevice, s));
-    // direction words (64 per row; dg_align_rows: q_len + 1 rows per pair and room for the walk's codes) for as many
-    // pairs at a time as fit the budget; inside a group one launch per kernel instance (cells per lane)
-    // (one wave per pair and ~1 us per row: what counts is how many pairs are in flight, so the budget is generous:
-    // a third of the free device memory, 96 GB at most; 8,192 waves fill the chip)
+    // Two passes (k_align.hip.h): every pair in the narrow band first; the pairs whose path came near an edge of it
+    // (DG_AL_RETRY) again in the full band.  Inside a pass: groups of as many pairs as fit the direction budget
+    // (one wave per pair and ~1 us per row: what counts is how many pairs are in flight; but a hipMalloc of tens
+    // of GB takes seconds on this platform, so 32 GB at most, a quarter of the free memory), and inside a group
+    // one launch per kernel instance (cells per lane).
     uint64_t budget_rows = (6ull << 30) / 256ull;
     {
         size_t mfree = 0, mtotal = 0;
         if (hipMemGetInfo(&mfree, &mtotal) == hipSuccess) {
             const uint64_t have = (uint64_t)mfree + (uint64_t)ddir.cap;      // (the buffer of the last call is ours to reuse)
-            budget_rows = std::min<uint64_t>(96ull << 30, std::max<uint64_t>(1ull << 30, have / 3)) / 256ull;
+            budget_rows = std::min<uint64_t>(32ull << 30, std::max<uint64_t>(1ull << 30, have / 4)) / 256ull;
         }
     }
+    if (const char *e = getenv("DAGCON_ALIGN_GB")) { const long long v = atoll(e); if (v >= 1 && v <= 200) budget_rows = ((uint64_t)v << 30) / 256ull; }
     if (const char *e = getenv("DAGCON_ALIGN_ROWS")) { const long long v = atoll(e); if (v >= 1) budget_rows = (uint64_t)v; }   // test knob
     const bool t_dbg = getenv("DAGCON_ALIGN_TIMING") != nullptr;
     if (t_dbg) HIPCHK(c, hipStreamSynchronize(s));
     double t_grp = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
-    DevBuf &didx = c->d_al[12];
-    ENSURE(c, didx, (size_t)n * 4);
-    std::vector<uint32_t> order(n);
-    uint32_t first = 0;
-    while (first < n) {
-        uint64_t rows = 0;
-        uint32_t cnt = 0;
-        while (first + cnt < n) {
-            const uint64_t r = dg_align_rows(q_len[first + cnt], t_len[first + cnt]);
-            if (cnt && rows + r > budget_rows) break;
-            dir_off[first + cnt] = rows;
-            rows += r; cnt++;
-        }
-        ENSURE(c, ddir, rows * 256ull);
-        HIPCHK(c, hipMemcpyAsync((uint64_t *)ddo.p + first, dir_off.data() + first, (size_t)cnt * 8, hipMemcpyHostToDevice, s));
-        // the group's pairs by kernel instance, the long ones first inside each
+    DevBuf &didx = c->d_al[12], &dhw = c->d_al[13];
+    ENSURE(c, didx, (size_t)n * 4); ENSURE(c, dhw, (size_t)n * 4);
+    std::vector<uint32_t> todo(n), halfw(n), order(n);
+    for (uint32_t a = 0; a < n; a++) todo[a] = a;
+    DgAlignParams ap;
+    ap.q = (const uint8_t *)dq.p; ap.t = (const uint8_t *)dt.p;
+    ap.q_off = (const uint64_t *)dqo.p; ap.t_off = (const uint64_t *)dto.p;
+    ap.q_len = (const uint32_t *)dql.p; ap.t_len = (const uint32_t *)dtl.p;
+    ap.out_off = (const uint64_t *)doo.p; ap.qaln = (uint8_t *)dqa.p; ap.taln = (uint8_t *)dta.p;
+    ap.aln_len = (uint32_t *)dlen.p; ap.dir_off = (const uint64_t *)ddo.p; ap.halfw = (const uint32_t *)dhw.p;
+    for (int pass = 0; pass < 2 && !todo.empty(); pass++) {
+        // (a pair whose first band is the full one already is final in the first pass: its width says so)
+        for (uint32_t a : todo) halfw[a] = pass == 0 ? dg_align_halfwidth_first(q_len[a], t_len[a]) : dg_align_halfwidth(q_len[a], t_len[a]);
+        HIPCHK(c, hipMemcpyAsync(dhw.p, halfw.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
         static const uint32_t kinds[6] = {2, 4, 6, 8, 12, 16};
-        uint32_t fill = 0, kbeg[7];
-        for (int k = 0; k < 6; k++) {
-            kbeg[k] = fill;
-            for (uint32_t x = 0; x < cnt; x++)
-                if (dg_align_cells(q_len[first + x], t_len[first + x]) == kinds[k]) order[first + fill++] = first + x;
-            std::stable_sort(order.begin() + first + kbeg[k], order.begin() + first + fill,
-                             [&](uint32_t x, uint32_t y) { return q_len[x] > q_len[y]; });
-        }
-        kbeg[6] = fill;
-        HIPCHK(c, hipMemcpyAsync((uint32_t *)didx.p + first, order.data() + first, (size_t)cnt * 4, hipMemcpyHostToDevice, s));
-        DgAlignParams ap;
-        ap.q = (const uint8_t *)dq.p; ap.t = (const uint8_t *)dt.p;
-        ap.q_off = (const uint64_t *)dqo.p; ap.t_off = (const uint64_t *)dto.p;
-        ap.q_len = (const uint32_t *)dql.p; ap.t_len = (const uint32_t *)dtl.p;
-        ap.out_off = (const uint64_t *)doo.p; ap.qaln = (uint8_t *)dqa.p; ap.taln = (uint8_t *)dta.p;
-        ap.aln_len = (uint32_t *)dlen.p; ap.dirs = (uint32_t *)ddir.p; ap.dir_off = (const uint64_t *)ddo.p;
-        for (int k = 0; k < 6; k++) {
-            const uint32_t nk = kbeg[k + 1] - kbeg[k];
-            if (!nk) continue;
-            ap.idx = (const uint32_t *)didx.p + first + kbeg[k]; ap.n = nk;
-            switch (kinds[k]) {
-                case 2: hipLaunchKernelGGL(k_align_band<2>, dim3(nk), dim3(64), 0, s, ap); break;
-                case 4: hipLaunchKernelGGL(k_align_band<4>, dim3(nk), dim3(64), 0, s, ap); break;
-                case 6: hipLaunchKernelGGL(k_align_band<6>, dim3(nk), dim3(64), 0, s, ap); break;
-                case 8: hipLaunchKernelGGL(k_align_band<8>, dim3(nk), dim3(64), 0, s, ap); break;
-                case 12: hipLaunchKernelGGL(k_align_band<12>, dim3(nk), dim3(64), 0, s, ap); break;
-                default: hipLaunchKernelGGL(k_align_band<16>, dim3(nk), dim3(64), 0, s, ap); break;
+        size_t first = 0;
+        while (first < todo.size()) {
+            uint64_t rows = 0;
+            size_t cnt = 0;
+            while (first + cnt < todo.size()) {
+                const uint32_t a = todo[first + cnt];
+                const uint64_t r = dg_align_rows(q_len[a], t_len[a], dg_align_cells(halfw[a]));
+                if (cnt && rows + r > budget_rows) break;
+                dir_off[a] = rows;
+                rows += r; cnt++;
             }
-            HIPCHK(c, hipGetLastError());
+            ENSURE(c, ddir, rows * 256ull);
+            ap.dirs = (uint32_t *)ddir.p;
+            HIPCHK(c, hipMemcpyAsync(ddo.p, dir_off.data(), (size_t)n * 8, hipMemcpyHostToDevice, s));
+            // the group's pairs by kernel instance, the long ones first inside each; two launches per instance when the
+            // pass is the first one: pairs whose narrow band IS the full band are final at once
+            size_t fill = 0;
+            for (int k = 0; k < 6; k++) {
+                for (int fin = 0; fin < 2; fin++) {
+                    const size_t k0 = fill;
+                    for (size_t x = 0; x < cnt; x++) {
+                        const uint32_t a = todo[first + x];
+                        const bool is_final = pass == 1 || halfw[a] == dg_align_halfwidth(q_len[a], t_len[a]);
+                        if (dg_align_cells(halfw[a]) == kinds[k] && (int)is_final == fin) order[first + fill++] = a;
+                    }
+                    const uint32_t nk = (uint32_t)(fill - k0);
+                    if (!nk) continue;
+                    std::stable_sort(order.begin() + first + k0, order.begin() + first + fill,
+                                     [&](uint32_t x, uint32_t y) { return q_len[x] > q_len[y]; });
+                    HIPCHK(c, hipMemcpyAsync((uint32_t *)didx.p + first + k0, order.data() + first + k0, (size_t)nk * 4, hipMemcpyHostToDevice, s));
+                    ap.idx = (const uint32_t *)didx.p + first + k0; ap.n = nk; ap.first_pass = fin ? 0u : 1u;
+                    switch (kinds[k]) {
+                        case 2: hipLaunchKernelGGL(k_align_band<2>, dim3(nk), dim3(64), 0, s, ap); break;
+                        case 4: hipLaunchKernelGGL(k_align_band<4>, dim3(nk), dim3(64), 0, s, ap); break;
+                        case 6: hipLaunchKernelGGL(k_align_band<6>, dim3(nk), dim3(64), 0, s, ap); break;
+                        case 8: hipLaunchKernelGGL(k_align_band<8>, dim3(nk), dim3(64), 0, s, ap); break;
+                        case 12: hipLaunchKernelGGL(k_align_band<12>, dim3(nk), dim3(64), 0, s, ap); break;
+                        default: hipLaunchKernelGGL(k_align_band<16>, dim3(nk), dim3(64), 0, s, ap); break;
+                    }
+                    HIPCHK(c, hipGetLastError());
+                }
+            }
+            HIPCHK(c, hipStreamSynchronize(s));       // (the direction buffer and the offsets are reused by the next group)
+            if (t_dbg) {
+                const double now = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+                fprintf(stderr, "dagcon_align: pass %d, group of %zu pairs, %.1f MB of directions: %.2f ms\n", pass, cnt, rows * 256.0 / 1e6, (now - t_grp) * 1e3);
+                t_grp = now;
+            }
+            first += cnt;
         }
-        HIPCHK(c, hipStreamSynchronize(s));       // (the direction buffer is reused by the next group)
-        if (t_dbg) {
-            const double now = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
-            fprintf(stderr, "dagcon_align: group of %u pairs, %.1f MB of directions: %.2f ms (upload + kernels)\n", cnt, rows * 256.0 / 1e6, (now - t_grp) * 1e3);
-            t_grp = now;
+        if (pass == 0) {
+            HIPCHK(c, d2h(c, aln_len, dlen.p, (size_t)n * 4));
+            std::vector<uint32_t> again;
+            for (uint32_t a = 0; a < n; a++) if (aln_len[a] == DG_AL_RETRY) again.push_back(a);
+            if (t_dbg) fprintf(stderr, "dagcon_align: %zu of %u pairs go to the full band\n", again.size(), n);
+            todo.swap(again);
         }
-        first += cnt;
     }
     HIPCHK(c, d2h(c, aln_len, dlen.p, (size_t)n * 4));
-    HIPCHK(c, d2h(c, qaln, dqa.p, out_bytes));
-    HIPCHK(c, d2h(c, taln, dta.p, out_bytes));
     for (uint32_t a = 0; a < n; a++)
         if ((uint64_t)aln_len[a] > (uint64_t)q_len[a] + t_len[a]) return fail(c, DAGCON_ERR_INTERNAL, "pair %u: alignment longer than its room", a);
+    *out_bytes_ret = out_bytes;
     return DAGCON_OK;
+}
+
+int dagcon_align(dagcon_ctx *ctx, uint32_t n, const uint64_t *q_off, const uint32_t *q_len,
+                 const uint64_t *t_off, const uint32_t *t_len, const char *q_blob, uint64_t q_bytes,
+                 const char *t_blob, uint64_t t_bytes, const uint64_t *out_off, char *qaln, char *taln,
+                 uint32_t *aln_len) {
+    if (!ctx) return DAGCON_ERR_INVALID_ARG;
+    Ctx *c = reinterpret_cast<Ctx *>(ctx);
+    if (n == 0) return DAGCON_OK;
+    if (!q_off || !q_len || !t_off || !t_len || !q_blob || !t_blob || !out_off || !qaln || !taln || !aln_len)
+        return fail(c, DAGCON_ERR_INVALID_ARG, "NULL argument");
+    uint64_t out_bytes = 0;
+    int r = align_device(c, n, q_off, q_len, t_off, t_len, q_blob, q_bytes, t_blob, t_bytes, out_off, aln_len, &out_bytes);
+    if (r != DAGCON_OK) return r;
+    HIPCHK(c, d2h(c, qaln, c->d_al[7].p, out_bytes));
+    HIPCHK(c, d2h(c, taln, c->d_al[8].p, out_bytes));
+    return DAGCON_OK;
+}
+
+// main.cpp:117-145 with -a in one call: every record re-aligned (SimpleAligner.cpp:25-63), start / end / strand as
+// SimpleAligner.cpp:51-62, then the usual path; the aligned strings never leave the device
+int dagcon_consensus_pre(dagcon_ctx *ctx, const dagcon_pre_batch *b, dagcon_results *results) {
+    if (!ctx || !b || !results) return DAGCON_ERR_INVALID_ARG;
+    Ctx *c = reinterpret_cast<Ctx *>(ctx);
+    const uint32_t T = b->n_targets;
+    if (T && (!b->tlen || !b->rec_begin)) return fail(c, DAGCON_ERR_INVALID_ARG, "tlen/rec_begin is NULL");
+    const uint64_t n64 = T ? b->rec_begin[T] : 0;
+    if (n64 > 0xFFFFFFF0ull) return fail(c, DAGCON_ERR_UNSUPPORTED, "too many records");
+    const uint32_t n = (uint32_t)n64;
+    if (n && (!b->tstart || !b->strand || !b->q_off || !b->q_len || !b->t_off || !b->t_len || !b->q_blob || !b->t_blob))
+        return fail(c, DAGCON_ERR_INVALID_ARG, "record arrays are NULL");
+    std::vector<uint64_t> out_off(n);
+    std::vector<uint32_t> alen(n, 0), start(n);
+    uint64_t tot = 0;
+    for (uint32_t a = 0; a < n; a++) { out_off[a] = tot; tot += ((uint64_t)b->q_len[a] + b->t_len[a] + 15ull) & ~15ull; }
+    uint64_t out_bytes = 0;
+    if (n) {
+        int r = align_device(c, n, b->q_off, b->q_len, b->t_off, b->t_len, b->q_blob, b->q_bytes, b->t_blob, b->t_bytes,
+                             out_off.data(), alen.data(), &out_bytes);
+        if (r != DAGCON_OK) return r;
+    }
+    // SimpleAligner.cpp:51-62 (the alignment is global: GenomicTBegin() = 0, GenomicTEnd() = |tseq|)
+    std::vector<uint32_t> rc_list;
+    for (uint32_t g = 0; g < T; g++) {
+        if (b->rec_begin[g + 1] < b->rec_begin[g] || b->rec_begin[g + 1] > n64) return fail(c, DAGCON_ERR_INVALID_ARG, "rec_begin not monotone at target %u", g);
+        for (uint64_t a = b->rec_begin[g]; a < b->rec_begin[g + 1]; a++) {
+            uint32_t st = b->tstart[a];
+            const uint32_t en = st + b->t_len[a];
+            if (b->strand[a] == '-') { st = b->tlen[g] - en; if (alen[a]) rc_list.push_back((uint32_t)a); }
+            start[a] = st + 1u;
+        }
+    }
+    if (!rc_list.empty()) {
+        DevBuf &didx = c->d_al[12];
+        HIPCHK(c, hipMemcpyAsync(didx.p, rc_list.data(), rc_list.size() * 4, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(k_align_revcomp, dim3((uint32_t)rc_list.size()), dim3(64), 0, c->stream,
+                           (uint8_t *)c->d_al[7].p, (uint8_t *)c->d_al[8].p, (const uint64_t *)c->d_al[6].p,
+                           (const uint32_t *)c->d_al[9].p, (const uint32_t *)didx.p);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipStreamSynchronize(c->stream));       // (rc_list is a local)
+    }
+    dagcon_batch db;
+    memset(&db, 0, sizeof db);
+    db.n_targets = T; db.tlen = b->tlen; db.aln_begin = b->rec_begin;
+    db.aln_start = start.data(); db.aln_off = out_off.data(); db.aln_len = alen.data();
+    db.blob_bytes = n ? out_bytes : 0;
+    int r = upload_impl(ctx, &db, n ? c->d_al[7].p : nullptr, n ? c->d_al[8].p : nullptr);
+    if (r != DAGCON_OK) return r;
+    if ((r = dagcon_run(ctx)) != DAGCON_OK) return r;
+    return dagcon_fetch(ctx, results);
 }
 
 int dagcon_host_alloc(dagcon_ctx *ctx, size_t bytes, void **out) {

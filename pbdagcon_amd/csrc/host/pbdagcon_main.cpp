@@ -196,7 +196,7 @@ double g_t_upload = 0, g_t_run = 0, g_t_fetch = 0;
 double wall() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 // one batch through the device; the records go to b.out (main.cpp:141-143), warnings to stderr
-int flush(dagcon_ctx *ctx, Batch &b, const Opts &o) {
+int flush(dagcon_ctx *ctx, Batch &b, const Opts &o, Blob *scratch) {
     if (b.ids.empty()) return 0;
     if (b.begin.back() != b.start.size()) b.begin.push_back(b.start.size());
     dagcon_batch db;
@@ -208,15 +208,40 @@ int flush(dagcon_ctx *ctx, Batch &b, const Opts &o) {
     // -a: SimpleAligner on every record first (main.cpp:127-128)
     std::vector<uint64_t> ooff;
     std::vector<uint32_t> alen, nstart;
-    std::string qa, ta;
-    if (o.align) {
+    char *qa = nullptr, *ta = nullptr;                  // -a: the aligned strings, in the worker's page-locked scratch
+    dagcon_results r;
+    int rc = DAGCON_OK;
+    bool have_results = false;
+    if (o.align && !o.polish) {
+        // main.cpp:117-145 with -a in one call: the aligned strings stay on the device
+        const size_t A = b.start.size();
+        dagcon_pre_batch pb;
+        memset(&pb, 0, sizeof pb);
+        pb.n_targets = db.n_targets; pb.tlen = b.tlen.data(); pb.rec_begin = b.begin.data();
+        pb.tstart = b.start.data(); pb.strand = b.strand.data();
+        pb.q_off = b.off.data(); pb.q_len = b.len.data(); pb.t_off = b.off2.data(); pb.t_len = b.len2.data();
+        pb.q_blob = b.q.data(); pb.q_bytes = b.q.size(); pb.t_blob = b.t.data(); pb.t_bytes = b.t.size();
+        const double ta0 = wall();
+        rc = dagcon_consensus_pre(ctx, &pb, &r);
+        if (g_timing) fprintf(stderr, "pbdagcon timing: -a batch of %zu records: dagcon_consensus_pre %.3f\n", A, wall() - ta0);
+        if (rc != DAGCON_OK) {
+            fprintf(stderr, "pbdagcon: alignment / consensus failed (%d): %s\n", rc, dagcon_last_error(ctx));
+            return 1;
+        }
+        have_results = true;
+    } else if (o.align) {
+        const double ta0 = wall();
         const size_t A = b.start.size();
         ooff.resize(A); alen.assign(A, 0); nstart.resize(A);
         uint64_t tot = 0;
         for (size_t a = 0; a < A; a++) { ooff[a] = tot; tot += (uint64_t)b.len[a] + b.len2[a]; }
-        qa.resize(tot + 1); ta.resize(tot + 1);
+        if (!scratch[0].resize(tot + 1, ctx) || !scratch[1].resize(tot + 1, ctx)) { fprintf(stderr, "pbdagcon: out of memory\n"); return 1; }
+        qa = scratch[0].data(); ta = scratch[1].data();
+        const double ta1 = wall();
         int rc = dagcon_align(ctx, (uint32_t)A, b.off.data(), b.len.data(), b.off2.data(), b.len2.data(), b.q.data(), b.q.size(),
                               b.t.data(), b.t.size(), ooff.data(), &qa[0], &ta[0], alen.data());
+        const double ta2 = wall();
+        if (g_timing) fprintf(stderr, "pbdagcon timing: -a batch of %zu records: buffers %.3f  dagcon_align %.3f\n", A, ta1 - ta0, ta2 - ta1);
         if (rc != DAGCON_OK) {
             fprintf(stderr, "pbdagcon: alignment failed (%d): %s\n", rc, dagcon_last_error(ctx));
             return 1;
@@ -236,11 +261,10 @@ int flush(dagcon_ctx *ctx, Batch &b, const Opts &o) {
             nstart[a] = start + 1;
         }
         db.aln_start = nstart.data(); db.aln_off = ooff.data(); db.aln_len = alen.data();
-        db.qstr = qa.data(); db.tstr = ta.data(); db.blob_bytes = tot;
+        db.qstr = qa; db.tstr = ta; db.blob_bytes = tot;
     }
-    dagcon_results r;
-    int rc;
-    if (g_timing) {                                       // the three steps of dagcon_consensus, timed apart
+    if (have_results) {
+    } else if (g_timing) {                                // the three steps of dagcon_consensus, timed apart
         const double t0 = wall();
         rc = dagcon_upload(ctx, &db);
         const double t1 = wall();
@@ -272,7 +296,7 @@ int flush(dagcon_ctx *ctx, Batch &b, const Opts &o) {
         const uint32_t pad = 64;
         std::vector<uint32_t> cur_start(A), cur_len(A), cur_qbase(A, 0);   // qbase: the read's base the current alignment begins with
         std::vector<uint64_t> cur_off(A);
-        std::string cur_q(qa), cur_t(ta);                  // the reads' last alignments, per record
+        std::string cur_q(qa, db.blob_bytes + 1), cur_t(ta, db.blob_bytes + 1);     // the reads' last alignments, per record
         for (size_t a = 0; a < A; a++) { cur_start[a] = db.aln_start[a]; cur_off[a] = db.aln_off[a]; cur_len[a] = db.aln_len[a]; }
         std::vector<uint64_t> p_qoff(A), p_toff(A), p_ooff(A), p_begin, p_bboff;
         std::vector<uint32_t> p_qlen(A), p_tlen(A), p_alen(A), p_tl, w0(A);
@@ -454,6 +478,7 @@ int main(int argc, char **argv) {
                 return;
             }
             { std::lock_guard<std::mutex> lk(mu); if (!pin_ctx) pin_ctx = ctx; }
+            Blob scratch[2];
             for (;;) {
                 Batch *b = nullptr;
                 {
@@ -463,7 +488,7 @@ int main(int argc, char **argv) {
                     b = work.front(); work.erase(work.begin());
                 }
                 const double tf0 = now();
-                const int st = flush(ctx, *b, o);
+                const int st = flush(ctx, *b, o, scratch);
                 const double tf = now() - tf0;
                 {
                     std::unique_lock<std::mutex> lk(mu);
@@ -494,6 +519,7 @@ int main(int argc, char **argv) {
                 for (auto &x : bufs) { if (x.q.owner == ctx) x.q.release(); if (x.t.owner == ctx) x.t.release(); }
                 if (pin_ctx == ctx) pin_ctx = nullptr;
             }
+            scratch[0].release(); scratch[1].release();
             dagcon_destroy(ctx);
         });
     }

@@ -8,8 +8,9 @@
 // SimpleAligner's parameters (SimpleAligner.cpp:10-23: match -5, mismatch +6, insertion 4,
 // deletion 5), ties resolved diagonal first, then insertion (gap in the target), then deletion,
 // inside a band of half-width dg_align_halfwidth() around the length-scaled diagonal
-// j = i * tlen / qlen (the role of GuidedAlign's band around the SDP chain).  The tests hold a bit-exact
-// CPU twin of it.
+// j = i * tlen / qlen (the role of GuidedAlign's band around the SDP chain); a narrower band is tried first and
+// stands when the path keeps away from its edges (dg_align_halfwidth_first).  The tests hold a bit-exact CPU
+// twin of it.
 //
 // One wave per alignment, the band of a row in REGISTERS: B = 2 W + 1 cells right-aligned on 64 lanes x C
 // cells (C = 2 .. 16, one kernel instance per C), lane l owning cells l C .. l C + C - 1 with their previous-row
@@ -51,14 +52,26 @@ __host__ __device__ inline uint32_t dg_align_halfwidth(uint32_t qlen, uint32_t t
     uint32_t w = 32u + 4u * dg_isqrt64((15ull * L + 99ull) / 100ull);
     return w > DG_AL_MAXW ? DG_AL_MAXW : w;
 }
-// cells per lane a pair needs, rounded up to a kernel instance (2, 4, 6, 8, 12, 16)
-__host__ __device__ inline uint32_t dg_align_cells(uint32_t qlen, uint32_t tlen) {
-    const uint32_t c = (2u * dg_align_halfwidth(qlen, tlen) + 1u + 63u) / 64u;
+// The band tried first: two of those.  The alignment found in it stands if its path keeps DG_AL_MARGIN
+// cells away from both edges of the band on every row; else the pair is done again in the full band
+// (dagcon_align: second pass).  Hardly a pair needs the full band: 1.8 x fewer cells, half the directions.
+__host__ __device__ inline uint32_t dg_align_halfwidth_first(uint32_t qlen, uint32_t tlen) {
+    const uint64_t L = qlen > tlen ? qlen : tlen;
+    const uint32_t w = 32u + 2u * dg_isqrt64((15ull * L + 99ull) / 100ull), full = dg_align_halfwidth(qlen, tlen);
+    return w > full ? full : w;
+}
+#define DG_AL_MARGIN 8
+#define DG_AL_RETRY 0xFFFFFFFFu   // aln_len of a pair whose path came too near an edge of the first band
+// cells per lane a band of half-width w needs, rounded up to a kernel instance (2, 4, 6, 8, 12, 16)
+__host__ __device__ inline uint32_t dg_align_cells(uint32_t w) {
+    const uint32_t c = (2u * w + 1u + 63u) / 64u;
     return c <= 2 ? 2u : c <= 4 ? 4u : c <= 6 ? 6u : c <= 8 ? 8u : c <= 12 ? 12u : 16u;
 }
-// rows of 64 words a pair takes in the direction buffer: its q_len + 1 rows, then one code per step of the walk
-__host__ __device__ inline uint64_t dg_align_rows(uint32_t qlen, uint32_t tlen) {
-    return (uint64_t)qlen + 1ull + ((uint64_t)qlen + tlen + 255ull) / 256ull + 1ull;
+// 256-byte units a pair takes in the direction buffer: q_len + 1 rows of 64 direction words (16-bit words up to
+// 8 cells per lane), then one code per step of the walk
+__host__ __device__ inline uint64_t dg_align_rows(uint32_t qlen, uint32_t tlen, uint32_t cells) {
+    const uint64_t row_bytes = cells <= 8u ? 128ull : 256ull;
+    return (((uint64_t)qlen + 1ull) * row_bytes + 255ull) / 256ull + ((uint64_t)qlen + tlen + 255ull) / 256ull + 1ull;
 }
 
 struct DgAlignParams {
@@ -69,8 +82,10 @@ struct DgAlignParams {
     uint8_t *qaln, *taln;          // written from the front of each alignment's room
     uint32_t *aln_len;
     uint32_t *dirs;                // direction words: 64 per row
-    const uint64_t *dir_off;       // per alignment, in rows (dg_align_rows of them)
+    const uint64_t *dir_off;       // per alignment, in 256-byte units (dg_align_rows of them)
     const uint32_t *idx;           // the alignments of this launch
+    const uint32_t *halfw;         // per alignment: half-width of the band of this pass
+    uint32_t first_pass;           // 1: a path near an edge of the band gives DG_AL_RETRY instead of an alignment
     uint32_t n;
 };
 
@@ -89,7 +104,8 @@ __device__ __forceinline__ int dg_al_dpp(int old, int src) {
 
 template <int C>
 __global__ __launch_bounds__(64) void k_align_band(DgAlignParams p) {
-    __shared__ uint32_t s_dir[DG_AL_ROWS * 64];
+    typedef typename std::conditional<(C <= 8), uint16_t, uint32_t>::type DirT;      // 2 bits per cell
+    __shared__ DirT s_dir[DG_AL_ROWS * 64];
     // the characters the row loop consumes one at a time (q[i - 1]; the t character that enters the band on its
     // right) come out of two 128-character LDS windows, refilled 64 at a time: a global load inside the row loop
     // would make every row wait for the previous row's direction store (gfx950 counts stores in vmcnt)
@@ -106,10 +122,11 @@ __global__ __launch_bounds__(64) void k_align_band(DgAlignParams p) {
         if (lane == 0) p.aln_len[a] = n + m;
         return;
     }
-    const int W = (int)dg_align_halfwidth(n, m), B = 2 * W + 1;
+    const int W = (int)p.halfw[a], B = 2 * W + 1;
     const int off = 64 * C - B;                             // dead cells in front of the band (host: B <= 64 C)
-    uint32_t *dirs = p.dirs + p.dir_off[a] * 64ull;
-    uint8_t *path = reinterpret_cast<uint8_t *>(dirs + ((uint64_t)n + 1ull) * 64ull);   // one code per step of the walk
+    DirT *dirs = reinterpret_cast<DirT *>(p.dirs + p.dir_off[a] * 64ull);
+    // one code per step of the walk, behind the rows (on a 256-byte boundary)
+    uint8_t *path = reinterpret_cast<uint8_t *>(p.dirs + p.dir_off[a] * 64ull) + ((((uint64_t)n + 1ull) * 64ull * sizeof(DirT) + 255ull) & ~255ull);
 
     // ---- forward: row i holds columns j = c_i - W + k, k = 0 .. B - 1, c_i = i m / n ----
     int P[C], T[C];
@@ -225,7 +242,7 @@ __global__ __launch_bounds__(64) void k_align_band(DgAlignParams p) {
             P[c] = valid ? sc : DG_AL_BIG;
             word |= d << (2 * c);
         }
-        dirs[(uint64_t)i * 64ull + (uint64_t)lane] = word;
+        dirs[(uint64_t)i * 64ull + (uint64_t)lane] = (DirT)word;
     };
     row(0u, std::true_type{});
     for (uint32_t i = 1; i <= n; i++) row(i, std::false_type{});
@@ -236,7 +253,7 @@ __global__ __launch_bounds__(64) void k_align_band(DgAlignParams p) {
     for (int c = 0; c < C; c++) if (kend % C == c) fin = P[c];
     fin = __builtin_amdgcn_readlane(fin, kend / C);
     if (fin >= DG_AL_LIM) {                                 // the band does not connect (0, 0) with (n, m)
-        if (lane == 0) p.aln_len[a] = 0;
+        if (lane == 0) p.aln_len[a] = p.first_pass ? DG_AL_RETRY : 0u;
         return;
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
@@ -248,7 +265,7 @@ __global__ __launch_bounds__(64) void k_align_band(DgAlignParams p) {
     int r0 = (int)n + 1;                                    // rows [r0, ..] are staged
     int codes = 0;
     const uint32_t cap = n + m;
-    bool bad = false;
+    bool bad = false, near_edge = false;
     while (i > 0 || j > 0) {
         if ((int)i < r0) {
             __syncthreads();
@@ -258,6 +275,7 @@ __global__ __launch_bounds__(64) void k_align_band(DgAlignParams p) {
         }
         const int k = (int)j - (wci - W) + off;
         if (k < off || k >= 64 * C || len >= cap) { bad = true; break; }     // cannot happen on a connected band
+        near_edge |= k - off < DG_AL_MARGIN || k - off > B - 1 - DG_AL_MARGIN;
         const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_dir[((int)i - r0) * 64 + k / C]);
         const uint32_t d = (w >> (2 * (k % C))) & 3u;
         if (d == 3u) { bad = true; break; }
@@ -275,7 +293,8 @@ __global__ __launch_bounds__(64) void k_align_band(DgAlignParams p) {
             j--;
         }
     }
-    if (bad) { if (lane == 0) p.aln_len[a] = 0; return; }
+    if (bad) { if (lane == 0) p.aln_len[a] = p.first_pass ? DG_AL_RETRY : 0u; return; }
+    if (near_edge && p.first_pass) { if (lane == 0) p.aln_len[a] = DG_AL_RETRY; return; }
     if ((uint32_t)lane < (len & 63u)) path[(len & ~63u) + (uint32_t)lane] = (uint8_t)codes;
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     __syncthreads();
@@ -296,4 +315,23 @@ __global__ __launch_bounds__(64) void k_align_band(DgAlignParams p) {
         iq -= (uint32_t)__popcll(mq); jt -= (uint32_t)__popcll(mt);
     }
     if (lane == 0) p.aln_len[a] = len;
+}
+
+// SimpleAligner.cpp:57-58 for the records of the '-' strand: both aligned strings reverse-complemented in place
+// (Alignment.cpp:15-26: upper-case A, C, G, T are complemented, everything else, the gaps too, only moves)
+__device__ __forceinline__ uint8_t dg_al_comp(uint8_t ch) {
+    return ch == 'A' ? 'T' : ch == 'C' ? 'G' : ch == 'G' ? 'C' : ch == 'T' ? 'A' : ch;
+}
+__global__ __launch_bounds__(64) void k_align_revcomp(uint8_t *qaln, uint8_t *taln, const uint64_t *out_off, const uint32_t *aln_len,
+                                                      const uint32_t *idx) {
+    const uint32_t a = idx[blockIdx.x];
+    const uint32_t len = aln_len[a];
+    for (int w = 0; w < 2; w++) {
+        uint8_t *sq = (w ? taln : qaln) + out_off[a];
+        for (uint32_t x = threadIdx.x; x < (len + 1u) / 2u; x += 64) {
+            const uint32_t y = len - 1u - x;
+            const uint8_t lo = sq[x], hi = sq[y];
+            sq[x] = dg_al_comp(hi); sq[y] = dg_al_comp(lo);       // (x == y: the middle one, complemented once)
+        }
+    }
 }

@@ -812,6 +812,34 @@ def test_cli_pre_input_with_align(tmp_path):
     assert out.stdout == b"".join(exp) and len(exp) == 3
 
 
+def test_consensus_pre_keeps_strings_on_the_device(gpu_ctx_factory):
+    """dagcon_consensus_pre (align, SimpleAligner.cpp:51-62 finish with the '-' strand reverse-complemented on
+    the device, then the usual path, nothing copied back in between) against the same steps on the CPU."""
+    rng = np.random.default_rng(77)
+    rc = bytes.maketrans(b"ACGT", b"TGCA")
+    targets, exp = [], []
+    for ti in range(5):
+        tlen = int(rng.integers(900, 2600))
+        target = bytes(b"ACGT"[j] for j in rng.integers(0, 4, tlen))
+        recs, alns = [], []
+        for r in range(9 if ti != 3 else 2):                        # target 3 stays below min_cov
+            s = int(rng.integers(0, tlen // 4)); e = int(rng.integers(3 * tlen // 4, tlen + 1))
+            strand = b"+-"[(r + ti) % 2:(r + ti) % 2 + 1]
+            tseq = target[s:e] if strand == b"+" else target[s:e].translate(rc)[::-1]
+            qseq = _mutate(rng, tseq)
+            tstart = s if strand == b"+" else tlen - e
+            recs.append((tstart, strand, qseq, tseq))
+            st, en, qa, ta = oracle.simple_align(tstart, tlen, strand, qseq, tseq)
+            alns.append((st, qa, ta))
+        targets.append((tlen, recs))
+        exp.append(oracle.consensus_target(tlen, alns, 500, 50, 6) if len(alns) >= 6 else [])
+    targets.append((1200, []))                                      # a target without records
+    exp.append([])
+    ctx = gpu_ctx_factory(min_cov=6, min_len=500, trim=50)
+    assert ctx.consensus_pre(targets) == exp
+    assert ctx.consensus_pre([]) == []
+
+
 def _polish_twin(tlen, recs, rounds, trim, min_cov, min_len, pad=64):
     """The steps of `pbdagcon -a --polish N` (csrc/host/pbdagcon_main.cpp) composed on the CPU:
     recs = [(tstart, strand, qseq, tseq, q_fwd)] of one target -> segments after `rounds` rounds."""
