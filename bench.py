@@ -26,8 +26,13 @@ Prints ONE JSON line on rank 0 (contract in the task statement), with
                   segments double as the whole-batch parity check
   h2d_inclusive : the same batch with the host->device copy of the strings inside
                   the clock (dagcon_consensus on a warm context); never `value`
-  e2e           : .m5 text of a slice of the workload on tmpfs -> the pbdagcon
-                  command line -> FASTA (file to FASTA, process start included)
+  two_contexts  : the timed workload again with two contexts in flight on the GPU (inputs
+                  resident): what a caller that keeps two batches in flight gets
+  streamed      : the same with every batch's host->device copy inside the clock
+  e2e           : .m5 text of the workload on tmpfs -> the pbdagcon command line ->
+                  FASTA (file to FASTA, process start included)
+  e2e_pre       : configs[2]'s surface: .pre text of 64 targets x 50 kb x 60x ->
+                  pbdagcon -a (re-alignment on the device) -> FASTA
 
 Other modes (not the driver's line):
   --stream-batches B   B batches of --targets targets through ONE GPU, two contexts
@@ -298,6 +303,49 @@ def e2e_leg(batch, n_targets, expect_fasta):
             pass
 
 
+def e2e_pre_leg(n_targets, tlen, coverage, opts):
+    """configs[2]'s input surface: .pre records (unaligned query / target substrings, Alignment.cpp:82-112) of
+    n_targets x tlen x coverage on tmpfs -> `pbdagcon -a` (every record re-aligned on the device, then the usual
+    path) -> FASTA.  The aligner is parity-unpinned beyond the reference's one KAT."""
+    from pbdagcon_amd import synth
+    exe = os.path.join(ROOT, "pbdagcon_amd", "bin", "pbdagcon")
+    if not os.path.exists(exe):
+        return None
+    tmpdir = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else "/tmp"
+    path = os.path.join(tmpdir, f"dagcon_bench_{os.getpid()}.pre")
+    try:
+        b = synth.make_batch(n_targets, tlen, coverage, seed=7000, threads=min(16, len(os.sched_getaffinity(0))))
+        with open(path, "wb") as f:
+            for t in range(b.n_targets):
+                tid = b.ids[t].encode()
+                for k, (start, q, tt) in enumerate(b.target_alignments(t)):
+                    ts = tt.replace(b"-", b"")
+                    f.write(b"q%07d_%d %s + %d %d %d %s %s\n" % (t, k, tid, int(b.tlen[t]), start - 1, start - 1 + len(ts),
+                                                                  q.replace(b"-", b""), ts))
+        size = os.path.getsize(path)
+        best = None
+        for _ in range(2):
+            t0 = time.perf_counter()
+            out = subprocess.run([exe, "-a", "-c", str(opts["min_cov"]), "-m", str(opts["min_len"]), "-t", str(opts["trim"]),
+                                  "-j", str(min(16, len(os.sched_getaffinity(0)))), path], capture_output=True)
+            dt = time.perf_counter() - t0
+            if out.returncode != 0:
+                return {"error": out.stderr.decode()[-300:]}
+            if best is None or dt < best[0]:
+                best = (dt, out.stdout)
+        dt, fasta = best
+        bases = sum(len(l) for l in fasta.split(b"\n") if l and not l.startswith(b">"))
+        return {"value": bases / dt, "unit": "bases/s", "targets": n_targets, "tlen": tlen, "coverage": coverage, "wall_s": dt,
+                "text_GBps": size / dt / 1e9, "pre_bytes": size,
+                "what": "pbdagcon_amd/bin/pbdagcon -a <file.pre on tmpfs> -> FASTA (config-3 shape), process start, parse, "
+                        "re-alignment of every record, consensus, formatting all inside the clock; best of 2"}
+    finally:
+        try:
+            os.unlink(path)
+        except OSError:
+            pass
+
+
 def load_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed PMC summary of this round (collected in
     separate --pmc passes, tools/pmc_summary.py); None when there is none for this workload."""
@@ -545,6 +593,8 @@ def worker(args, rank, world, local_rank):
                 }
             line["e2e"] = e2e_leg(batch, args.e2e_targets, fasta_bytes(batch.select(range(min(args.e2e_targets, batch.n_targets))),
                                                                       res[:args.e2e_targets]))
+            if n_gpus == 1 and config1:
+                line["e2e_pre"] = e2e_pre_leg(64, 50000, 60, dict(min_cov=8, min_len=500, trim=50))
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
