@@ -689,6 +689,12 @@ def test_cli_several_workers_and_a_bad_target(tmp_path):
     two = subprocess.run([cli, "-j", "2", "--devices", "0,0", "--batch-targets", "2", "--pinned", "1", str(path)],
                          capture_output=True, timeout=300)
     assert two.returncode == 0 and two.stdout == exp, two.stderr.decode()
+    # --contexts: several workers per GPU (what long inputs get by default), text taken a small slab at a time so
+    # that consumed text is dropped while later batches are still being parsed
+    three = subprocess.run([cli, "-j", "3", "--contexts", "3", "--batch-targets", "1", "--slab-bytes", "40000", str(path)],
+                           capture_output=True, timeout=300, env=dict(os.environ, PBDAGCON_TIMING="1"))
+    assert three.returncode == 0 and three.stdout == exp, three.stderr.decode()
+    assert b"pbdagcon timing: total" in three.stderr
     # break one alignment of target 5: tStart beyond the target
     lines = m5.decode().splitlines()
     f = lines[53].split(" ")

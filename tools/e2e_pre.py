@@ -28,4 +28,4 @@ for rep in range(2):
     print(f"run {rep}: rc {out.returncode}, {dt:.2f} s wall, {bases} consensus bases, {bases / dt / 1e6:.2f} M bases/s end to end, "
           f"{size / dt / 1e6:.0f} MB/s of .pre", flush=True)
     print(out.stderr.decode()[-700:].strip())
-os.unlink(path)
+if not os.environ.get("E2E_KEEP"): os.unlink(path)
