@@ -149,9 +149,9 @@ __global__ __launch_bounds__(64) void k_align_band(DgAlignParams p) {
     int ci = 0;
     int tcur = (int)s_tw[0];                                // the next character to enter
     int qc = -1, qcn = (int)s_qw[0];                        // q[i - 1] of this row, of the next
-    auto row = [&](const uint32_t i, auto first_row) {
-        constexpr bool FIRST = decltype(first_row)::value;
-        if constexpr (!FIRST) {
+    // the band moves on to row i: scores and characters follow, q[i - 1] is fetched
+    auto advance = [&](const uint32_t i) {
+        {
             num += m;
             uint32_t shift = 0;
             while (num >= n) { num -= n; shift++; }
@@ -195,6 +195,11 @@ __global__ __launch_bounds__(64) void k_align_band(DgAlignParams p) {
             }
             qcn = (int)s_qw[i & 127u];                                              // q[i]: the next row's
         }
+    };
+    // row i.  EDGE: the band hangs over an end of t on this row (columns < 0 or > m are not cells); rows in the
+    // middle, the bulk, skip the test
+    auto row = [&](const uint32_t i, auto first_row, auto edge_row) {
+        constexpr bool FIRST = decltype(first_row)::value, EDGE = decltype(edge_row)::value;
         // A = min(diagonal, insertion) of the lane's cells
         const int left = dg_al_dpp<DG_DPP_WAVE_SHR1, 0xf>(DG_AL_BIG, P[C - 1]);     // the lane in front: its last cell
         int A[C];
@@ -204,7 +209,7 @@ __global__ __launch_bounds__(64) void k_align_band(DgAlignParams p) {
 #pragma unroll
         for (int c = 0; c < C; c++) {
             const int j = jl + c;
-            const bool valid = (uint32_t)j <= m && kb + c >= off;
+            const bool valid = (!EDGE || (uint32_t)j <= m) && kb + c >= off;
             int best;
             if constexpr (FIRST) best = j == 0 ? 0 : DG_AL_BIG;
             else {
@@ -232,7 +237,7 @@ __global__ __launch_bounds__(64) void k_align_band(DgAlignParams p) {
 #pragma unroll
         for (int c = 0; c < C; c++) {
             const int j = jl + c;
-            const bool valid = (uint32_t)j <= m && kb + c >= off;
+            const bool valid = (!EDGE || (uint32_t)j <= m) && kb + c >= off;
             const int x = A[c] - DG_AL_DEL * (kb + c);
             // deletion (left) wins only when strictly better than diagonal / insertion
             const bool del = j > 0 && pm < x;
@@ -244,8 +249,12 @@ __global__ __launch_bounds__(64) void k_align_band(DgAlignParams p) {
         }
         dirs[(uint64_t)i * 64ull + (uint64_t)lane] = (DirT)word;
     };
-    row(0u, std::true_type{});
-    for (uint32_t i = 1; i <= n; i++) row(i, std::false_type{});
+    row(0u, std::true_type{}, std::true_type{});
+    for (uint32_t i = 1; i <= n; i++) {
+        advance(i);
+        if (ci >= W && ci + W <= (int)m) row(i, std::false_type{}, std::false_type{});
+        else row(i, std::false_type{}, std::true_type{});
+    }
     // (n, m) is cell k = W of the last row
     const int kend = W + off;
     int fin = DG_AL_BIG;
