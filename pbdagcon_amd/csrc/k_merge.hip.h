@@ -1186,7 +1186,10 @@ __global__ __launch_bounds__(PF ? 128 : 64) __attribute__((amdgpu_waves_per_eu(8
 // last vertex or DG_NOSEG_END) triples, a target's segments in a row and in order): one wave per
 // entry.  Entries are taken by ticket, so a worker that waits for the earlier segments of its target
 #define DG_NOSEG_END 0xFFFFFFFFu
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_merge_list(DgParams p) {
+#ifndef DG_ML_WAVES
+#define DG_ML_WAVES 8
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DG_ML_WAVES, DG_ML_WAVES))) void k_merge_list(DgParams p) {
     if (dg_failed(p)) return;
     const uint32_t n = p.tile_list[0] < p.tile_list_cap ? p.tile_list[0] : p.tile_list_cap;
     for (;;) {
