@@ -37,15 +37,15 @@ def test_struct_layouts_match_header():
     prog = r'''
 #include <stdio.h>
 #include "dagcon.h"
-int main(void){printf("%zu %zu %zu %zu %zu\n", sizeof(dagcon_opts), sizeof(dagcon_batch),
- sizeof(dagcon_results), sizeof(dagcon_timings), sizeof(dagcon_graph_dump)); return 0;}
+int main(void){printf("%zu %zu %zu %zu %zu %zu\n", sizeof(dagcon_opts), sizeof(dagcon_batch),
+ sizeof(dagcon_results), sizeof(dagcon_timings), sizeof(dagcon_graph_dump), sizeof(dagcon_pre_batch)); return 0;}
 '''
     with tempfile.TemporaryDirectory() as d:
         open(os.path.join(d, "s.c"), "w").write(prog)
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), "-o", os.path.join(d, "s"),
                                os.path.join(d, "s.c")])
         out = subprocess.check_output([os.path.join(d, "s")]).split()
-    got = [ctypes.sizeof(x) for x in (capi.Opts, capi.Batch, capi.Results, capi.Timings, capi.GraphDump)]
+    got = [ctypes.sizeof(x) for x in (capi.Opts, capi.Batch, capi.Results, capi.Timings, capi.GraphDump, capi.PreBatch)]
     assert got == [int(x) for x in out]
 
 

@@ -844,6 +844,12 @@ def test_consensus_pre_keeps_strings_on_the_device(gpu_ctx_factory):
     ctx = gpu_ctx_factory(min_cov=6, min_len=500, trim=50)
     assert ctx.consensus_pre(targets) == exp
     assert ctx.consensus_pre([]) == []
+    # a record that leaves its target (tstart + |tseq| > tlen) fails that target alone
+    tl0, recs0 = targets[0]
+    bad = [(tl0, [(tl0 - 10,) + recs0[0][1:]] + recs0[1:])] + targets[1:]
+    got = ctx.consensus_pre(bad, strict=False)
+    assert got[0] == [] and got[1:] == exp[1:]
+    assert ctx.target_status[0] == -4 and not ctx.target_status[1:].any()
 
 
 def _polish_twin(tlen, recs, rounds, trim, min_cov, min_len, pad=64):
