@@ -20,6 +20,7 @@
 #include "k_build.hip.h"
 #include "k_merge.hip.h"
 #include "k_merge_tile.hip.h"
+#include "k_merge_q.hip.h"
 #include "k_bestpath.hip.h"
 #include "k_align.hip.h"
 
@@ -40,6 +41,7 @@ struct Ctx {
 
     // host copy of the filtered batch
     uint32_t T = 0, A = 0;
+    int merge_q = 1, use_q = 0;                    // k_merge_q: four segments per wave (DAGCON_MERGE_Q=0: never); this batch
     uint32_t max_k = 0, max_tlen = 0;
     uint64_t sum_len = 0, sum_bb = 0, mat_cells = 0, blob_bytes = 0;
     bool have_bb = false;
@@ -309,6 +311,7 @@ int launch_all(Ctx *c) {
             hipLaunchKernelGGL(k_merge_tile, dim3(c->T, c->tile_ny), dim3(DG_T_LANES), c->tile_words * 4, s, p);
             hipLaunchKernelGGL(k_merge_list, dim3(c->list_grid), dim3(64), 0, s, p);
         } else if (p.pf_ahead) hipLaunchKernelGGL(k_merge<true>, dim3(c->T * c->seg_max), dim3(128), 0, s, p);
+        else if (c->use_q) hipLaunchKernelGGL(k_merge_q, dim3((c->T * c->seg_max + 3u) / 4u), dim3(64), 0, s, p);
         else hipLaunchKernelGGL(k_merge<false>, dim3(c->T * c->seg_max), dim3(64), 0, s, p);
     }
     HIPCHK(c, hipEventRecord(c->ev[3], s));
@@ -375,6 +378,7 @@ int dagcon_create(const dagcon_opts *opts, dagcon_ctx **out) {
         const int v = atoi(e);
         if (v >= 1 && v <= 64) c->seg_env = (uint32_t)v;
     }
+    if (const char *e = getenv("DAGCON_MERGE_Q")) c->merge_q = atoi(e) != 0;     // four segments per wave (k_merge_q.hip.h)
     memset(&c->tm, 0, sizeof c->tm);
     memset(&c->h_st, 0, sizeof c->h_st);
     if (hipSetDevice(c->device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
@@ -424,23 +428,6 @@ static int upload_impl(dagcon_ctx *ctx, const dagcon_batch *b, const void *dev_q
     HIPCHK(c, hipSetDevice(c->device));
 
     c->T = T;
-    // merge workers per target: about one chip's worth of resident waves (8 per SIMD x 1024
-    // SIMDs) over the batch, never fewer than 8 nor more than 64 per target
-    if (c->opts.max_segments) c->seg_max = c->opts.max_segments > 64u ? 64u : c->opts.max_segments;
-    else if (c->seg_env) c->seg_max = c->seg_env;
-    else { uint32_t sm = T ? 8192u / T : 8u; c->seg_max = sm < 8u ? 8u : sm > 64u ? 64u : sm; }
-    // bestPath is swept in three times as many pieces: its waves are light (one piece = one
-    // sequential sweep when that is asked for)
-    c->bp_max = c->seg_max == 1 ? 1u : std::min(64u, 3u * c->seg_max);
-    if (const char *e = getenv("DAGCON_BP_SEGS")) { const int v = atoi(e); if (v >= 1 && v <= 64) c->bp_max = (uint32_t)v; }
-    // scratch per (target, piece): 4096 words where that is cheap, less for batches of very many
-    // targets (2 GB in all at most; a piece that needs more raises DG_E_STACK: grown x4, re-run)
-    {
-        const uint64_t pieces = std::max<uint64_t>(1, (uint64_t)T * c->bp_max);
-        const uint32_t fit = (uint32_t)std::min<uint64_t>(4096, (512ull << 20) / pieces);
-        const uint32_t base = std::max(256u, fit);
-        if (c->stk_words < base || (uint64_t)c->stk_words * pieces > (1024ull << 20)) c->stk_words = base;
-    }
     c->h_tlen.assign(b->tlen, b->tlen + T);
     c->h_aln_begin.assign(T + 1, 0);
     c->h_tactive.assign(T, 0);
@@ -504,6 +491,37 @@ static int upload_impl(dagcon_ctx *ctx, const dagcon_batch *b, const void *dev_q
     if (!c->seg_min) c->seg_min = (uint32_t)std::min<uint64_t>(768, std::max<uint64_t>(192, c->sum_bb / 8192));
     c->gcuts = c->full_span ? 0u : 1u;
     if (const char *e = getenv("DAGCON_GCUTS")) c->gcuts = atoi(e) ? 1u : 0u;
+    // merge workers per target: about one chip's worth of resident waves (8 per SIMD x 1024
+    // SIMDs) over the batch, never fewer than 8 nor more than 64 per target
+    if (c->opts.max_segments) c->seg_max = c->opts.max_segments > 64u ? 64u : c->opts.max_segments;
+    else if (c->seg_env) c->seg_max = c->seg_env;
+    else { uint32_t sm = T ? 8192u / T : 8u; c->seg_max = sm < 8u ? 8u : sm > 64u ? 64u : sm; }
+    // k_merge_q (four segments per wave, DQ_WAVES waves per SIMD) for full-span batches big enough to fill the chip with
+    // it: as many pieces as go (<= 64 per target) with its waves filling the chip a whole number of times -- a last round
+    // that is a third full costs as much as a full one (configs[1]: 36 / 49 / 56 / 64 pieces 20.6 / 17.4 / 19.2 / 18.3 ms)
+    c->use_q = 0;
+    if (c->merge_q && !c->gcuts && c->seg_max != 1) {
+        const uint32_t slots = 1024u * DQ_WAVES;
+        if (c->opts.max_segments || c->seg_env) c->use_q = 1;                       // (the caller's number of pieces)
+        else if (T >= slots / 16u) {
+            const uint32_t k = T * 16u / slots;                                      // rounds at 64 pieces per target
+            c->seg_max = std::min<uint32_t>(64u, k * slots * 4u / T);
+            c->use_q = 1;
+        }
+    }
+    if (c->use_q && !c->opts.min_segment_len) c->seg_min = 128;                     // (its pieces are a quarter of a wave's work)
+    // bestPath is swept in three times as many pieces: its waves are light (one piece = one
+    // sequential sweep when that is asked for)
+    c->bp_max = c->seg_max == 1 ? 1u : std::min(64u, 3u * c->seg_max);
+    if (const char *e = getenv("DAGCON_BP_SEGS")) { const int v = atoi(e); if (v >= 1 && v <= 64) c->bp_max = (uint32_t)v; }
+    // scratch per (target, piece): 4096 words where that is cheap, less for batches of very many
+    // targets (2 GB in all at most; a piece that needs more raises DG_E_STACK: grown x4, re-run)
+    {
+        const uint64_t pieces = std::max<uint64_t>(1, (uint64_t)T * c->bp_max);
+        const uint32_t fit = (uint32_t)std::min<uint64_t>(4096, (512ull << 20) / pieces);
+        const uint32_t base = std::max(256u, fit);
+        if (c->stk_words < base || (uint64_t)c->stk_words * pieces > (1024ull << 20)) c->stk_words = base;
+    }
     if (c->gcuts) c->tile_list_cap = std::max<uint32_t>(c->tile_list_cap, (uint32_t)std::min<uint64_t>((uint64_t)T * c->seg_max + 64, 0x0FFFFFFFull));
     // LDS tiles for mergeNodes: positions per tile from the LDS budget and the expected size of a
     // position's share of the graph (exact after the first run of a shape)
