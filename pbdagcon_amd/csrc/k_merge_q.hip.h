@@ -339,9 +339,6 @@ __device__ __forceinline__ void dq_merge_segment(const DgParams &p, const uint32
     if (lane == 0) { g.queue[0] = c_start; s_ring[0] = c_start; }
     DQ_FENCE();
     bool failed = false;
-    int u_next = 0;
-    bool have_next = false;
-    uint4 nxl = make_uint4(0, 0, 0, 0), nxh = make_uint4(0, 0, 0, 0);     // record of u_next, requested early
     // Two phases per round, so that the rows of a wave spend their time on the same code: (A) every row runs
     // through the visits that merge nothing (one look, the FIFO bookkeeping) until it meets a visit that has a merge
     // group, or a list longer than half a row, to deal with -- rows that have met theirs wait; (B) those visits, by
@@ -351,18 +348,16 @@ __device__ __forceinline__ void dq_merge_segment(const DgParams &p, const uint32
         int u = -1;
         bool need = false, skip_in = false, in_only = false;
         while (qh < qt && !failed) {
-            const bool pre = have_next;
-            if (have_next) u = u_next;
-            else if (qt - qh <= DQ_RING) u = s_ring[qh & (DQ_RING - 1)];
+            if (qt - qh <= DQ_RING) u = s_ring[qh & (DQ_RING - 1)];
             else u = g.queue[qh];
-            have_next = false;
             qh++;
             if (u < c_start || u > c_hi) { dq_fail(g, DG_E_INTERNAL, lane); failed = true; break; }      // cannot happen (see k_cuts)
             skip_in = c_start != 0 && u == c_start;        // the previous segment's worker merges in[u]
             in_only = u == c_end;                          // ... which is this, for the next segment
             if (in_only && qh != qt) { dq_fail(g, DG_E_INTERNAL, lane); failed = true; break; }
-            uint4 ul, uh;
-            if (pre) { ul = nxl; uh = nxh; } else { ul = dg_lo16(&DG_NV(g, u)); uh = dg_hi16(&DG_NV(g, u)); }
+            // (k_merge asks for the next vertex's record before this visit's stores go out; here the 8 registers that
+            // takes cost more, in waves per SIMD, than the round trip: 17.3 ms with, 16.1 without at configs[1])
+            const uint4 ul = dg_lo16(&DG_NV(g, u)), uh = dg_hi16(&DG_NV(g, u));
             const int eff_in = skip_in ? 0 : DG_H_INLEN(ul), eff_out = in_only ? 0 : DG_H_OUTLEN(ul);
             if (eff_in > DQ_W / 2 || eff_out > DQ_W / 2) { need = true; break; }
             const bool is_in = lane < DQ_W / 2;
@@ -390,13 +385,6 @@ __device__ __forceinline__ void dq_merge_segment(const DgParams &p, const uint32
             const bool live = valid && !is_in;
             const int pend = DG_H_PEND(h) - 1;
             const qmask rm = dq_ballot(live && pend == 0);
-            // the next vertex to visit is known now: the queue's head, or the first vertex this visit enqueues
-            if (qh < qt) {
-                if (qt - qh <= DQ_RING) { u_next = s_ring[qh & (DQ_RING - 1)]; have_next = true; }
-            } else if (rm) {
-                u_next = dq_rl(nbr, __ffs((int)rm) - 1); have_next = true;
-            }
-            if (have_next) { nxl = dg_lo16(&DG_NV(g, u_next)); nxh = dg_hi16(&DG_NV(g, u_next)); }
             if (live) DG_NV(g, nbr).pending = pend;
             if (live && pend == 0) {
                 const uint32_t pos = qt + (uint32_t)__popc(rm & DQ_LT(lane));
@@ -446,7 +434,6 @@ __device__ __forceinline__ void dq_merge_segment(const DgParams &p, const uint32
             });
         }
         if (in_only) break;                               // the next segment's worker does the rest of this visit
-        have_next = false;
         // ---------------- mergeOutNodes(u) + FIFO bookkeeping ----------------
         bool done = false;
         if (scalar) {
