@@ -474,7 +474,7 @@ def worker(args, rank, world, local_rank):
     if rank == 0:
         ms = {k: sum(v) / len(v) for k, v in stage.items()}
         dom = max(("ms_normalize", "ms_build", "ms_merge", "ms_bestpath"), key=lambda k: ms[k])
-        dom_kernel = {"ms_normalize": "k_norm_chunk", "ms_build": "k_emit", "ms_merge": "k_merge", "ms_bestpath": "k_bp_sweep"}[dom]
+        dom_kernel = {"ms_normalize": "k_norm_chunk", "ms_build": "k_emit", "ms_merge": "k_merge_q", "ms_bestpath": "k_bp_sweep"}[dom]
         alg = tm["algorithmic_bytes"]
         achieved = alg / (ms[dom] * 1e-3) / 1e9
         config1 = args.targets == 1000 and args.tlen == 10000 and args.coverage == 40

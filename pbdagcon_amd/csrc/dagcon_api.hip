@@ -162,7 +162,7 @@ int ensure_arenas(Ctx *c) {
     ENSURE(c, c->d_bp_tt, c->node_cap * 4);
     ENSURE(c, c->d_cns_tmp, c->node_cap);
     ENSURE(c, c->d_pool, c->pool_cap * 4);
-    ENSURE(c, c->d_stk, std::max<uint64_t>((uint64_t)c->T * c->bp_max, (c->tile_pos || c->gcuts) ? c->list_grid : 0) * c->stk_words * 4);       // (bp_max >= seg_max)
+    ENSURE(c, c->d_stk, std::max<uint64_t>((uint64_t)c->T * std::max(c->bp_max, c->seg_max), (c->tile_pos || c->gcuts) ? c->list_grid : 0) * c->stk_words * 4);
     if (c->tile_pos) ENSURE(c, c->d_nextcut, c->sum_bb * 4);
     if (c->tile_pos || c->gcuts) ENSURE(c, c->d_tile_list, (4ull + 3ull * c->tile_list_cap) * 4);
     if (c->gcuts) {
@@ -497,16 +497,20 @@ static int upload_impl(dagcon_ctx *ctx, const dagcon_batch *b, const void *dev_q
     else if (c->seg_env) c->seg_max = c->seg_env;
     else { uint32_t sm = T ? 8192u / T : 8u; c->seg_max = sm < 8u ? 8u : sm > 64u ? 64u : sm; }
     // k_merge_q (four segments per wave, DQ_WAVES waves per SIMD) for full-span batches big enough to fill the chip with
-    // it: as many pieces as go (<= 64 per target) with its waves filling the chip a whole number of times -- a last round
+    // it: as many pieces as go (<= 256 per target) with its waves filling the chip a whole number of times -- a last round
     // that is a third full costs as much as a full one (configs[1]: 36 / 49 / 56 / 64 pieces 20.6 / 17.4 / 19.2 / 18.3 ms)
     c->use_q = 0;
     if (c->merge_q && !c->gcuts && c->seg_max != 1) {
         const uint32_t slots = 1024u * DQ_WAVES;
         if (c->opts.max_segments || c->seg_env) c->use_q = 1;                       // (the caller's number of pieces)
-        else if (T >= slots / 16u) {
-            const uint32_t k = T * 16u / slots;                                      // rounds at 64 pieces per target
-            c->seg_max = std::min<uint32_t>(64u, k * slots * 4u / T);
-            c->use_q = 1;
+        else if (T) {
+            // pieces a target can give: up to 256, one per 128 positions of the average backbone
+            const uint64_t avail = std::min<uint64_t>(256, std::max<uint64_t>(1, c->sum_bb / T / 128));
+            const uint64_t k = (uint64_t)T * avail / 4u / slots;                     // whole rounds at that many pieces
+            if (k >= 1 || (uint64_t)T * avail / 4u * 10u >= 9u * slots) {            // (or one round nine tenths full)
+                c->seg_max = (uint32_t)std::min<uint64_t>(avail, std::max<uint64_t>(k, 1) * slots * 4u / T);
+                c->use_q = 1;
+            }
         }
     }
     if (c->use_q && !c->opts.min_segment_len) c->seg_min = 128;                     // (its pieces are a quarter of a wave's work)
@@ -517,7 +521,7 @@ static int upload_impl(dagcon_ctx *ctx, const dagcon_batch *b, const void *dev_q
     // scratch per (target, piece): 4096 words where that is cheap, less for batches of very many
     // targets (2 GB in all at most; a piece that needs more raises DG_E_STACK: grown x4, re-run)
     {
-        const uint64_t pieces = std::max<uint64_t>(1, (uint64_t)T * c->bp_max);
+        const uint64_t pieces = std::max<uint64_t>(1, (uint64_t)T * std::max(c->bp_max, c->seg_max));
         const uint32_t fit = (uint32_t)std::min<uint64_t>(4096, (512ull << 20) / pieces);
         const uint32_t base = std::max(256u, fit);
         if (c->stk_words < base || (uint64_t)c->stk_words * pieces > (1024ull << 20)) c->stk_words = base;
