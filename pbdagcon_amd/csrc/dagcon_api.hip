@@ -311,7 +311,7 @@ int launch_all(Ctx *c) {
             hipLaunchKernelGGL(k_merge_tile, dim3(c->T, c->tile_ny), dim3(DG_T_LANES), c->tile_words * 4, s, p);
             hipLaunchKernelGGL(k_merge_list, dim3(c->list_grid), dim3(64), 0, s, p);
         } else if (p.pf_ahead) hipLaunchKernelGGL(k_merge<true>, dim3(c->T * c->seg_max), dim3(128), 0, s, p);
-        else if (c->use_q) hipLaunchKernelGGL(k_merge_q, dim3((c->T * c->seg_max + 3u) / 4u), dim3(64), 0, s, p);
+        else if (c->use_q) hipLaunchKernelGGL(k_merge_q, dim3((c->T * c->seg_max + DQ_ROWS - 1u) / DQ_ROWS), dim3(64), 0, s, p);
         else hipLaunchKernelGGL(k_merge<false>, dim3(c->T * c->seg_max), dim3(64), 0, s, p);
     }
     HIPCHK(c, hipEventRecord(c->ev[3], s));
@@ -506,9 +506,9 @@ static int upload_impl(dagcon_ctx *ctx, const dagcon_batch *b, const void *dev_q
         else if (T) {
             // pieces a target can give: up to 256, one per 128 positions of the average backbone
             const uint64_t avail = std::min<uint64_t>(256, std::max<uint64_t>(1, c->sum_bb / T / 128));
-            const uint64_t k = (uint64_t)T * avail / 4u / slots;                     // whole rounds at that many pieces
-            if (k >= 1 || (uint64_t)T * avail / 4u * 10u >= 9u * slots) {            // (or one round nine tenths full)
-                c->seg_max = (uint32_t)std::min<uint64_t>(avail, std::max<uint64_t>(k, 1) * slots * 4u / T);
+            const uint64_t k = (uint64_t)T * avail / DQ_ROWS / slots;                     // whole rounds at that many pieces
+            if (k >= 1 || (uint64_t)T * avail / DQ_ROWS * 10u >= 9u * slots) {            // (or one round nine tenths full)
+                c->seg_max = (uint32_t)std::min<uint64_t>(avail, std::max<uint64_t>(k, 1) * slots * DQ_ROWS / T);
                 c->use_q = 1;
             }
         }

@@ -15,11 +15,16 @@
 #include <hip/hip_runtime.h>
 #include "dagcon_dev.h"
 
+#ifndef DQ_W
 #define DQ_W 16                      // lanes of a row
+#endif
+#define DQ_ROWS (64 / DQ_W)          // rows (segments) of a wave
+#define DQ_ALL ((uint32_t)((1ull << DQ_W) - 1ull))
+#define DQ_LO ((1u << (DQ_W / 2)) - 1u)   // the lower half of a row: in entries of the one-look path
 #define DQ_RING 128                  // the youngest queue entries of a row, in LDS
 typedef uint32_t qmask;              // one bit per lane of the row
 
-__device__ __forceinline__ qmask dq_ballot(bool p) { return (qmask)((__ballot(p) >> (threadIdx.x & 48u)) & 0xffffull); }
+__device__ __forceinline__ qmask dq_ballot(bool p) { return (qmask)((__ballot(p) >> (threadIdx.x & (64u - DQ_W))) & (unsigned long long)DQ_ALL); }
 __device__ __forceinline__ int dq_rl(int v, int l) { return __shfl(v, l, DQ_W); }          // lane l of the caller's row
 #define DQ_LT(lane) ((1u << (lane)) - 1u)
 // a row's earlier stores before its later loads (a single lane's, on the literal path)
@@ -372,7 +377,7 @@ __device__ __forceinline__ void dq_merge_segment(const DgParams &p, const uint32
             const qmask cand = dq_ballot(valid && ((h.x >> (is_in ? 0u : 16u)) & 0xffffu) == 1u);
             // a merge group = two candidates of one side with the same base
             bool work = false;
-            if (__popc(cand & 0xffu) >= 2 || __popc(cand & 0xff00u) >= 2) {
+            if (__popc(cand & DQ_LO) >= 2 || __popc(cand & (DQ_ALL & ~DQ_LO)) >= 2) {
                 const int key = ((cand >> lane) & 1u) ? (DG_H_BASE(h) | (is_in ? 0 : 256)) : -1 - lane;
                 for (qmask m = cand; m && !work; m &= m - 1u) {
                     const int kf = dq_rl(key, __ffs((int)m) - 1);
@@ -455,7 +460,7 @@ __device__ __forceinline__ void dq_merge_segment(const DgParams &p, const uint32
                 int b = 256;
                 if (__popc(cand) >= 2) b = dq_pick_group(cand, DG_H_BASE(h), last_out, lane, &M);
                 if (b != 256) {
-                    if (dq_merge_out_group(g, u, DG_H2_OUTOFF(uh), M, d, cnt, h, valid, 0xffffu, lane)) {
+                    if (dq_merge_out_group(g, u, DG_H2_OUTOFF(uh), M, d, cnt, h, valid, DQ_ALL, lane)) {
                         last_out = b;
                         continue;                         // re-read u's list, look for the next group
                     }
@@ -507,10 +512,10 @@ __device__ __forceinline__ void dq_merge_segment(const DgParams &p, const uint32
 #define DQ_WAVES 6
 #endif
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DQ_WAVES, DQ_WAVES))) void k_merge_q(DgParams p) {
-    __shared__ int s_stk[4][2 * DQ_IN_STACK];
-    __shared__ int s_ring[4][DQ_RING];
-    const uint32_t row = threadIdx.x >> 4;
-    const uint32_t pair = blockIdx.x * 4u + row;
+    __shared__ int s_stk[DQ_ROWS][2 * DQ_IN_STACK];
+    __shared__ int s_ring[DQ_ROWS][DQ_RING];
+    const uint32_t row = threadIdx.x / DQ_W;
+    const uint32_t pair = blockIdx.x * DQ_ROWS + row;
     const uint32_t t = pair / p.seg_max, seg = pair % p.seg_max;
     if (t >= p.T) return;
     if (dg_failed(p) || dg_tskip(p, t)) return;
