@@ -295,7 +295,7 @@ int launch_all(Ctx *c) {
     }
     HIPCHK(c, hipEventRecord(c->ev[2], s));
     if (c->T > 0 && !(c->opts.flags & DAGCON_FLAG_STOP_AFTER_BUILD)) {
-        hipLaunchKernelGGL(k_cuts, dim3(c->T), dim3(64), 0, s, p);
+        if (!c->gcuts || c->tile_pos) hipLaunchKernelGGL(k_cuts, dim3(c->T), dim3(64), 0, s, p);      // (k_cuts2 makes its own, bestPath's too)
         if (c->gcuts && !c->tile_pos) {
             // partial-span cuts: enter and what hangs on it first, then the segments as a worklist, exit last
             HIPCHK(c, hipMemsetAsync(c->d_tile_list.p, 0, 16, s));
