@@ -506,7 +506,9 @@ static int upload_impl(dagcon_ctx *ctx, const dagcon_batch *b, const void *dev_q
     if (c->merge_q && !c->gcuts && c->seg_max != 1) {
         const uint32_t slots = 1024u * DQ_WAVES;
         if (c->opts.max_segments || c->seg_env) c->use_q = 1;                       // (the caller's number of pieces)
-        else if (T) {
+        // a row holds 8 + 8 list entries in its one-look path and 16 in the generic one: past ~70 reads per target
+        // too many visits outgrow it (600 targets x 6 kb: 60x 8.9 ms against k_merge's 11.4, 100x 30.6 against 17.8)
+        else if (T && c->h_aln_len.size() <= 72ull * T) {
             // pieces a target can give: up to 256, one per 128 positions of the average backbone
             const uint64_t avail = std::min<uint64_t>(256, std::max<uint64_t>(1, c->sum_bb / T / 128));
             const uint64_t k = (uint64_t)T * avail / DQ_ROWS / slots;                     // whole rounds at that many pieces
