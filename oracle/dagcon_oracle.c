@@ -296,6 +296,89 @@ static size_t og_banded_align_w(const char *q, uint32_t n, const char *t, uint32
     return len;
 }
 
+/* The band tried before either of those: OG_AL_WA cells to either side of a centre that FOLLOWS the alignment -- row i's
+ * band starts s_i = clamp(a + 1 - OG_AL_WA, 0, 2) columns to the right of row i - 1's, a = the (first) cell of row i - 1
+ * with the smallest score: the band's centre sits on the diagonal successor of the best prefix alignment so far.  Returns
+ * the alignment, or *fallback = 1 when the band lost the corner (n, m), a row had no reachable cell, or the path came
+ * within OG_AL_MARGIN cells of an edge: the static bands decide then. */
+#define OG_AL_WA 56
+static size_t og_adaptive_align(const char *q, uint32_t n, const char *t, uint32_t m, char *qaln, char *taln, int *fallback) {
+    const int32_t W = OG_AL_WA, B = 2 * W + 1;
+    *fallback = 1;
+    int32_t *prev = (int32_t *)malloc(sizeof(int32_t) * B), *cur = (int32_t *)malloc(sizeof(int32_t) * B);
+    uint8_t *dir = (uint8_t *)malloc((size_t)(n + 1) * B), *sh = (uint8_t *)malloc((size_t)n + 1);
+    int64_t lo = -(int64_t)W;
+    size_t len = 0;
+    int ok = 1;
+    for (uint32_t i = 0; i <= n && ok; i++) {
+        int32_t s = 0;
+        if (i > 0) {
+            int32_t a = -1, best = OG_AL_INF;
+            for (int32_t k = 0; k < B; k++) if (prev[k] < best) { best = prev[k]; a = k; }
+            if (a < 0) { ok = 0; break; }
+            s = a + 1 - W; if (s < 0) s = 0; if (s > 2) s = 2;
+            lo += s;
+        }
+        sh[i] = (uint8_t)s;
+        for (int32_t k = 0; k < B; k++) {
+            const int64_t j = lo + k;
+            int32_t best = OG_AL_INF; uint8_t d = 3;
+            if (j >= 0 && j <= (int64_t)m) {
+                if (i == 0 && j == 0) { best = 0; d = 3; }
+                if (i > 0 && j > 0) {
+                    const int32_t kp = k + s - 1;
+                    if (kp >= 0 && kp < B && prev[kp] < OG_AL_INF) {
+                        const int32_t v = prev[kp] + (q[i - 1] == t[j - 1] ? OG_AL_MATCH : OG_AL_MISMATCH);
+                        if (v < best) { best = v; d = 0; }
+                    }
+                }
+                if (i > 0) {
+                    const int32_t kp = k + s;
+                    if (kp >= 0 && kp < B && prev[kp] < OG_AL_INF) {
+                        const int32_t v = prev[kp] + OG_AL_INS;
+                        if (v < best) { best = v; d = 1; }
+                    }
+                }
+                if (j > 0 && k > 0 && cur[k - 1] < OG_AL_INF) {
+                    const int32_t v = cur[k - 1] + OG_AL_DEL;
+                    if (v < best) { best = v; d = 2; }
+                }
+            }
+            cur[k] = best;
+            dir[(size_t)i * B + k] = d;
+        }
+        int32_t *x = prev; prev = cur; cur = x;
+    }
+    if (ok) {
+        const int64_t kend = (int64_t)m - lo;
+        if (kend < 0 || kend >= B || prev[kend] >= OG_AL_INF) ok = 0;
+    }
+    if (ok) {
+        char *rq = (char *)malloc((size_t)n + m + 1), *rt = (char *)malloc((size_t)n + m + 1);
+        uint32_t i = n, j = m;
+        int touched = 0;
+        while (i > 0 || j > 0) {
+            const int64_t kk = (int64_t)j - lo;
+            if (kk < 0 || kk >= B) { touched = 1; break; }
+            if (kk < OG_AL_MARGIN || kk > (int64_t)B - 1 - OG_AL_MARGIN) touched = 1;
+            const uint8_t d = dir[(size_t)i * B + (size_t)kk];
+            if (d == 0) { rq[len] = q[i - 1]; rt[len] = t[j - 1]; lo -= sh[i]; i--; j--; }
+            else if (d == 1) { rq[len] = q[i - 1]; rt[len] = '-'; lo -= sh[i]; i--; }
+            else if (d == 2) { rq[len] = '-'; rt[len] = t[j - 1]; j--; }
+            else { touched = 1; break; }
+            len++;
+        }
+        if (!touched) {
+            for (size_t k = 0; k < len; k++) { qaln[k] = rq[len - 1 - k]; taln[k] = rt[len - 1 - k]; }
+            qaln[len] = taln[len] = 0;
+            *fallback = 0;
+        }
+        free(rq); free(rt);
+    }
+    free(prev); free(cur); free(dir); free(sh);
+    return *fallback ? 0 : len;
+}
+
 size_t og_banded_align(const char *q, uint32_t n, const char *t, uint32_t m, char *qaln, char *taln) {
     if (n == 0 || m == 0) {
         size_t k = 0;
@@ -306,6 +389,11 @@ size_t og_banded_align(const char *q, uint32_t n, const char *t, uint32_t m, cha
     }
     const uint32_t w1 = og_align_halfwidth_first(n, m), w2 = og_align_halfwidth(n, m);
     int touched = 0;
+    if (w1 > OG_AL_WA && !getenv("OG_NO_ADAPTIVE")) {          /* (a static band that narrow already: nothing to gain) */
+        int fb = 0;
+        const size_t la = og_adaptive_align(q, n, t, m, qaln, taln, &fb);
+        if (!fb) return la;
+    }
     size_t len = og_banded_align_w(q, n, t, m, w1, qaln, taln, &touched);
     /* near an edge, or no path at all inside the narrow band: the full band decides */
     if (w1 < w2 && (touched || len == 0)) len = og_banded_align_w(q, n, t, m, w2, qaln, taln, &touched);

@@ -65,9 +65,10 @@ int og_parse_pre(const char *line, size_t len, og_parsed *out, uint32_t *end_out
  * reproduces: a global alignment that minimises blasr's distance score (SimpleAligner.cpp:10-23:
  * match -5, mismatch +6 from SMRTDistanceMatrix, insertion 4, deletion 5), ties resolved
  * diagonal first, then insertion (gap in the target), then deletion, inside a band of half-width
- * og_align_halfwidth(qlen, tlen) around the length-scaled diagonal j = i * tlen / qlen.  The band of
- * og_align_halfwidth_first() is tried first: what it finds stands when the path keeps 8 cells away from its
- * edges, else the full band decides.
+ * og_align_halfwidth(qlen, tlen) around the length-scaled diagonal j = i * tlen / qlen.  Narrower bands are tried
+ * first and stand when the path keeps 8 cells away from their edges: a band of 56 cells to either side of a centre
+ * that follows the best cell of the row before (pairs long enough for the static bands to be wider than that), then
+ * the static band of og_align_halfwidth_first(), then the full one.
  * Outputs (capacity qlen + tlen + 1 each) get the aligned strings; returns their length. */
 uint32_t og_align_halfwidth(uint32_t qlen, uint32_t tlen);
 uint32_t og_align_halfwidth_first(uint32_t qlen, uint32_t tlen);   /* the band tried first (see og_banded_align) */

@@ -969,6 +969,47 @@ static int align_device(Ctx *c, uint32_t n, const uint64_t *q_off, const uint32_
     ap.q_len = (const uint32_t *)dql.p; ap.t_len = (const uint32_t *)dtl.p;
     ap.out_off = (const uint64_t *)doo.p; ap.qaln = (uint8_t *)dqa.p; ap.taln = (uint8_t *)dta.p;
     ap.aln_len = (uint32_t *)dlen.p; ap.dir_off = (const uint64_t *)ddo.p; ap.halfw = (const uint32_t *)dhw.p;
+    // the band that follows the alignment first (k_align_adapt): every pair long enough for a static band wider than it
+    {
+        std::vector<uint32_t> ad, rest;
+        for (uint32_t a = 0; a < n; a++) (dg_align_halfwidth_first(q_len[a], t_len[a]) > DG_AL_WA ? ad : rest).push_back(a);
+        if (getenv("DAGCON_ALIGN_STATIC")) { rest.insert(rest.end(), ad.begin(), ad.end()); ad.clear(); }      // test knob
+        std::stable_sort(ad.begin(), ad.end(), [&](uint32_t x, uint32_t y) { return q_len[x] > q_len[y]; });
+        size_t first = 0;
+        while (first < ad.size()) {
+            uint64_t rows = 0;
+            size_t cnt = 0;
+            while (first + cnt < ad.size()) {
+                const uint32_t a = ad[first + cnt];
+                const uint64_t r = dg_align_rows_adapt(q_len[a], t_len[a]);
+                if (cnt && rows + r > budget_rows) break;
+                dir_off[a] = rows;
+                rows += r; cnt++;
+            }
+            ENSURE(c, ddir, rows * 256ull);
+            ap.dirs = (uint32_t *)ddir.p;
+            HIPCHK(c, hipMemcpyAsync(ddo.p, dir_off.data(), (size_t)n * 8, hipMemcpyHostToDevice, s));
+            HIPCHK(c, hipMemcpyAsync((uint32_t *)didx.p + first, ad.data() + first, cnt * 4, hipMemcpyHostToDevice, s));
+            ap.idx = (const uint32_t *)didx.p + first; ap.n = (uint32_t)cnt; ap.first_pass = 1u;
+            hipLaunchKernelGGL(k_align_adapt, dim3((uint32_t)cnt), dim3(64), 0, s, ap);
+            HIPCHK(c, hipGetLastError());
+            HIPCHK(c, hipStreamSynchronize(s));
+            if (t_dbg) {
+                const double now = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+                fprintf(stderr, "dagcon_align: following band, group of %zu pairs, %.1f MB of directions: %.2f ms\n", cnt, rows * 256.0 / 1e6, (now - t_grp) * 1e3);
+                t_grp = now;
+            }
+            first += cnt;
+        }
+        if (!ad.empty()) {
+            HIPCHK(c, d2h(c, aln_len, dlen.p, (size_t)n * 4));
+            size_t back = 0;
+            for (uint32_t a : ad) if (aln_len[a] == DG_AL_RETRY) { rest.push_back(a); back++; }
+            if (t_dbg) fprintf(stderr, "dagcon_align: %zu of %zu pairs go on to the static bands\n", back, ad.size());
+        }
+        std::sort(rest.begin(), rest.end());
+        todo.swap(rest);
+    }
     for (int pass = 0; pass < 2 && !todo.empty(); pass++) {
         // (a pair whose first band is the full one already is final in the first pass: its width says so)
         for (uint32_t a : todo) halfw[a] = pass == 0 ? dg_align_halfwidth_first(q_len[a], t_len[a]) : dg_align_halfwidth(q_len[a], t_len[a]);
@@ -1027,7 +1068,7 @@ static int align_device(Ctx *c, uint32_t n, const uint64_t *q_off, const uint32_
         if (pass == 0) {
             HIPCHK(c, d2h(c, aln_len, dlen.p, (size_t)n * 4));
             std::vector<uint32_t> again;
-            for (uint32_t a = 0; a < n; a++) if (aln_len[a] == DG_AL_RETRY) again.push_back(a);
+            for (uint32_t a : todo) if (aln_len[a] == DG_AL_RETRY) again.push_back(a);
             if (t_dbg) fprintf(stderr, "dagcon_align: %zu of %u pairs go to the full band\n", again.size(), n);
             todo.swap(again);
         }

@@ -8,9 +8,9 @@
 // SimpleAligner's parameters (SimpleAligner.cpp:10-23: match -5, mismatch +6, insertion 4,
 // deletion 5), ties resolved diagonal first, then insertion (gap in the target), then deletion,
 // inside a band of half-width dg_align_halfwidth() around the length-scaled diagonal
-// j = i * tlen / qlen (the role of GuidedAlign's band around the SDP chain); a narrower band is tried first and
-// stands when the path keeps away from its edges (dg_align_halfwidth_first).  The tests hold a bit-exact CPU
-// twin of it.
+// j = i * tlen / qlen (the role of GuidedAlign's band around the SDP chain); narrower bands are tried first and
+// stand when the path keeps away from their edges: a band that follows the alignment (k_align_adapt), then a static
+// one (dg_align_halfwidth_first).  The tests hold a bit-exact CPU twin of all of it.
 //
 // One wave per alignment, the band of a row in REGISTERS: B = 2 W + 1 cells right-aligned on 64 lanes x C
 // cells (C = 2 .. 16, one kernel instance per C), lane l owning cells l C .. l C + C - 1 with their previous-row
@@ -308,6 +308,206 @@ __global__ __launch_bounds__(64) void k_align_band(DgAlignParams p) {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     __syncthreads();
     // ---- the characters, 64 steps at a time: step s consumed q[i_s - 1] and / or t[j_s - 1] ----
+    uint32_t iq = n, jt = m;
+    for (uint32_t s0 = 0; s0 < len; s0 += 64) {
+        const uint32_t s = s0 + (uint32_t)lane;
+        const bool on = s < len;
+        const uint32_t d = on ? path[s] : 3u;
+        const bool uq = on && d != 2u, ut = on && d != 1u;
+        const unsigned long long mq = __ballot(uq), mt = __ballot(ut);
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        const uint32_t myi = iq - (uint32_t)__popcll(mq & lt), myj = jt - (uint32_t)__popcll(mt & lt);
+        if (on) {
+            qo[len - 1u - s] = uq ? q[myi - 1u] : (uint8_t)'-';
+            to[len - 1u - s] = ut ? t[myj - 1u] : (uint8_t)'-';
+        }
+        iq -= (uint32_t)__popcll(mq); jt -= (uint32_t)__popcll(mt);
+    }
+    if (lane == 0) p.aln_len[a] = len;
+}
+
+// ---- the band tried before the static ones: DG_AL_WA cells to either side of a centre that FOLLOWS the alignment ----
+// Row i's band starts s_i = clamp(a + 1 - DG_AL_WA, 0, 2) columns to the right of row i - 1's, a = the first cell of row
+// i - 1 with the smallest score: the centre sits on the diagonal successor of the best prefix alignment so far.  113
+// cells per row instead of 300 - 960: two per lane (the structure of k_align_band<2>), 4 bits of direction per lane
+// (a byte; lane 0, whose cells lie in front of the band, keeps s_i there for the walk back).  DG_AL_RETRY when the
+// band loses the corner (n, m), a row has no reachable cell, or the path comes within DG_AL_MARGIN cells of an edge:
+// the static bands decide then (dagcon_align's later passes).  On the synthetic pairs the alignment is the static
+// band's, byte for byte, and no pair falls back.
+#define DG_AL_WA 56
+__host__ __device__ inline uint64_t dg_align_rows_adapt(uint32_t qlen, uint32_t tlen) {
+    return (((uint64_t)qlen + 1ull) * 64ull + 255ull) / 256ull + ((uint64_t)qlen + tlen + 255ull) / 256ull + 1ull;
+}
+__global__ __launch_bounds__(64) void k_align_adapt(DgAlignParams p) {
+    constexpr int C = 2, W = DG_AL_WA, B = 2 * W + 1, off = 64 * C - B;
+    __shared__ uint8_t s_dir[DG_AL_ROWS * 64];
+    __shared__ uint8_t s_qw[128], s_tw[128];
+    const uint32_t a = p.idx[blockIdx.x];
+    const int lane = threadIdx.x;
+    const uint32_t n = p.q_len[a], m = p.t_len[a];
+    const uint8_t *q = p.q + p.q_off[a], *t = p.t + p.t_off[a];
+    uint8_t *qo = p.qaln + p.out_off[a], *to = p.taln + p.out_off[a];
+    if (n == 0 || m == 0) {
+        for (uint32_t i = lane; i < n; i += 64) { qo[i] = q[i]; to[i] = '-'; }
+        for (uint32_t j = lane; j < m; j += 64) { qo[n + j] = '-'; to[n + j] = t[j]; }
+        if (lane == 0) p.aln_len[a] = n + m;
+        return;
+    }
+    uint8_t *dirs = reinterpret_cast<uint8_t *>(p.dirs + p.dir_off[a] * 64ull);
+    uint8_t *path = dirs + ((((uint64_t)n + 1ull) * 64ull + 255ull) & ~255ull);
+    int P[C], T[C];
+    int jl = -W - off + lane * C;                           // column of the lane's first cell
+#pragma unroll
+    for (int c = 0; c < C; c++) {
+        const int j = jl + c;
+        P[c] = DG_AL_BIG;
+        T[c] = (j >= 1 && j <= (int)m) ? (int)t[j - 1] : 0;
+    }
+    const int tw0 = W;
+    uint32_t tr = 0;
+    for (int x = lane; x < 128; x += 64) {
+        s_tw[x] = (uint32_t)(tw0 + x) < m ? t[tw0 + x] : (uint8_t)0;
+        s_qw[x] = (uint32_t)x < n ? q[x] : (uint8_t)0;
+    }
+    DG_AL_WAIT_LOADS();
+    int tcur = (int)s_tw[0];
+    int qc = -1, qcn = (int)s_qw[0];
+    int lo = -W;                                            // column of the band's first cell
+    bool lost = false;
+    const int kb = lane * C;
+    for (uint32_t i = 0; i <= n; i++) {
+        uint32_t shift = 0;
+        if (i > 0) {
+            // where the previous row's best cell is (its first one)
+            int mn = P[0] < P[1] ? P[0] : P[1], v;
+            v = dg_al_dpp<DG_DPP_ROW_SHR(1), 0xf>(DG_AL_BIG, mn); mn = v < mn ? v : mn;
+            v = dg_al_dpp<DG_DPP_ROW_SHR(2), 0xf>(DG_AL_BIG, mn); mn = v < mn ? v : mn;
+            v = dg_al_dpp<DG_DPP_ROW_SHR(4), 0xf>(DG_AL_BIG, mn); mn = v < mn ? v : mn;
+            v = dg_al_dpp<DG_DPP_ROW_SHR(8), 0xf>(DG_AL_BIG, mn); mn = v < mn ? v : mn;
+            v = dg_al_dpp<DG_DPP_BCAST15, 0xa>(DG_AL_BIG, mn); mn = v < mn ? v : mn;
+            v = dg_al_dpp<DG_DPP_BCAST31, 0xc>(DG_AL_BIG, mn); mn = v < mn ? v : mn;
+            const int best = __builtin_amdgcn_readlane(mn, 63);
+            if (best >= DG_AL_LIM) { lost = true; break; }
+            const unsigned long long b0 = __ballot(P[0] == best), b1 = __ballot(P[1] == best);
+            const int k0 = b0 ? 2 * (__ffsll((long long)b0) - 1) : 1 << 20, k1 = b1 ? 2 * (__ffsll((long long)b1) - 1) + 1 : 1 << 20;
+            const int am = (k0 < k1 ? k0 : k1) - off;
+            int sft = am + 1 - W;
+            sft = sft < 0 ? 0 : sft > 2 ? 2 : sft;
+            shift = (uint32_t)sft;
+            for (uint32_t s = 0; s < shift; s++) {
+                lo++; jl++;
+                const int newc = tcur;
+                tr++;
+                if ((tr & 63u) == 0 && tr >= 64u) {
+                    const uint32_t r = tr + 64u + (uint32_t)lane;
+                    s_tw[r & 127u] = (uint32_t)tw0 + r < m ? t[(uint32_t)tw0 + r] : (uint8_t)0;
+                    DG_AL_WAIT_LOADS();
+                }
+                tcur = (int)s_tw[tr & 127u];
+                int pin = dg_al_dpp<DG_DPP_WAVE_SHL1, 0xf>(DG_AL_BIG, P[0]);
+                int tin = dg_al_dpp<DG_DPP_WAVE_SHL1, 0xf>(0, T[0]);
+                if (lane == 63) { pin = DG_AL_BIG; tin = newc; }
+                P[0] = P[1]; T[0] = T[1];
+                P[1] = pin; T[1] = tin;
+            }
+            qc = qcn;
+            if ((i & 63u) == 0 && i >= 64u) {
+                const uint32_t r = i + 64u + (uint32_t)lane;
+                s_qw[r & 127u] = r < n ? q[r] : (uint8_t)0;
+                DG_AL_WAIT_LOADS();
+            }
+            qcn = (int)s_qw[i & 127u];
+        }
+        const int left = dg_al_dpp<DG_DPP_WAVE_SHR1, 0xf>(DG_AL_BIG, P[C - 1]);
+        int A[C];
+        uint32_t dbits = 0;
+        int lm = DG_AL_BIG;
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            const int j = jl + c;
+            const bool valid = (uint32_t)j <= m && kb + c >= off;
+            int best;
+            if (i == 0) best = j == 0 ? 0 : DG_AL_BIG;
+            else {
+                const int dg = (c == 0 ? left : P[c - 1]) + (T[c] == qc ? DG_AL_MATCH : DG_AL_MISMATCH);
+                const int up = P[c] + DG_AL_INS;
+                const bool ins = up < dg;
+                best = ins ? up : dg;
+                dbits |= ins ? 1u << c : 0u;
+            }
+            best = valid ? best : DG_AL_BIG;
+            A[c] = best;
+            const int x = best - DG_AL_DEL * (kb + c);
+            lm = x < lm ? x : lm;
+        }
+        int incl = lm, v;
+        v = dg_al_dpp<DG_DPP_ROW_SHR(1), 0xf>(DG_AL_BIG, incl); incl = v < incl ? v : incl;
+        v = dg_al_dpp<DG_DPP_ROW_SHR(2), 0xf>(DG_AL_BIG, incl); incl = v < incl ? v : incl;
+        v = dg_al_dpp<DG_DPP_ROW_SHR(4), 0xf>(DG_AL_BIG, incl); incl = v < incl ? v : incl;
+        v = dg_al_dpp<DG_DPP_ROW_SHR(8), 0xf>(DG_AL_BIG, incl); incl = v < incl ? v : incl;
+        v = dg_al_dpp<DG_DPP_BCAST15, 0xa>(DG_AL_BIG, incl); incl = v < incl ? v : incl;
+        v = dg_al_dpp<DG_DPP_BCAST31, 0xc>(DG_AL_BIG, incl); incl = v < incl ? v : incl;
+        int pm = dg_al_dpp<DG_DPP_WAVE_SHR1, 0xf>(DG_AL_BIG, incl);
+        uint32_t word = 0;
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            const int j = jl + c;
+            const bool valid = (uint32_t)j <= m && kb + c >= off;
+            const int x = A[c] - DG_AL_DEL * (kb + c);
+            const bool del = j > 0 && pm < x;
+            const int sc = del ? pm + DG_AL_DEL * (kb + c) : A[c];
+            const uint32_t d = del ? 2u : (dbits >> c) & 1u;
+            pm = x < pm ? x : pm;
+            P[c] = valid ? sc : DG_AL_BIG;
+            word |= d << (2 * c);
+        }
+        if (lane == 0) word = shift;                        // (its cells lie in front of the band)
+        dirs[(uint64_t)i * 64ull + (uint64_t)lane] = (uint8_t)word;
+    }
+    // (n, m) must be a reachable cell of the last row
+    const int kend = (int)m - lo + off;
+    bool fail = lost || kend < off || kend >= 64 * C;
+    if (!fail) {
+        int fin = (kend & 1) ? P[1] : P[0];
+        fin = __builtin_amdgcn_readlane(fin, kend / C);
+        fail = fin >= DG_AL_LIM;
+    }
+    if (fail) { if (lane == 0) p.aln_len[a] = DG_AL_RETRY; return; }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    // ---- walk back (uniform), rows of directions through LDS ----
+    uint32_t i = n, j = m, len = 0;
+    int r0 = (int)n + 1, codes = 0;
+    const uint32_t cap = n + m;
+    bool bad = false;
+    while (i > 0 || j > 0) {
+        if ((int)i < r0) {
+            __syncthreads();
+            r0 = (int)i >= DG_AL_ROWS - 1 ? (int)i - (DG_AL_ROWS - 1) : 0;
+            for (uint32_t x = lane; x < ((uint32_t)((int)i - r0) + 1u) * 64u; x += 64) s_dir[x] = dirs[(uint64_t)r0 * 64ull + x];
+            __syncthreads();
+        }
+        const int k = (int)j - lo + off;
+        if (k < off + DG_AL_MARGIN || k > off + B - 1 - DG_AL_MARGIN || len >= cap) { bad = true; break; }
+        const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_dir[((int)i - r0) * 64 + k / C]);
+        const uint32_t d = (w >> (2 * (k % C))) & 3u;
+        if (d == 3u) { bad = true; break; }
+        codes = (uint32_t)lane == (len & 63u) ? (int)d : codes;
+        len++;
+        if ((len & 63u) == 0) path[len - 64u + (uint32_t)lane] = (uint8_t)codes;
+        if (d != 2u) {
+            if (i == 0) { bad = true; break; }
+            lo -= (int)__builtin_amdgcn_readfirstlane((int)s_dir[((int)i - r0) * 64]);      // s_i
+            i--;
+        }
+        if (d != 1u) {
+            if (j == 0) { bad = true; break; }
+            j--;
+        }
+    }
+    if (bad) { if (lane == 0) p.aln_len[a] = DG_AL_RETRY; return; }
+    if ((uint32_t)lane < (len & 63u)) path[(len & ~63u) + (uint32_t)lane] = (uint8_t)codes;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __syncthreads();
     uint32_t iq = n, jt = m;
     for (uint32_t s0 = 0; s0 < len; s0 += 64) {
         const uint32_t s = s0 + (uint32_t)lane;
