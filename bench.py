@@ -449,9 +449,9 @@ def worker(args, rank, world, local_rank):
     cpu = None
     verified, verified_targets = None, 0
     if not args.no_verify or not args.no_cpu:
-        # rank 0 runs the oracle over its whole shard (that run is also the cpu_baseline leg); the
-        # other ranks check a sample of theirs
-        n_chk = args.cpu_sample if rank == 0 else min(16, batch.n_targets)
+        # at N = 1 rank 0 runs the oracle over its whole shard (that run is also the cpu_baseline leg); at N > 1
+        # every rank checks a sample of its shard
+        n_chk = args.cpu_sample if rank == 0 and n_gpus == 1 else min(64 if rank == 0 else 16, batch.n_targets)
         v, n, cdt, segs = cpu_baseline(batch, n_chk, opts, cores)
         verified = segs == res[:n]
         verified_targets = n
@@ -519,7 +519,7 @@ def worker(args, rank, world, local_rank):
             "fasta_gather_ok": gather_ok,
             "fasta_sha256": hashlib.sha256(my_fasta).hexdigest() if n_gpus == 1 else None,
         }
-        if cpu is not None and not args.no_cpu:
+        if cpu is not None and not args.no_cpu and n_gpus == 1:      # (the CPU legs belong to the N = 1 line)
             v, n, cdt = cpu
             line["cpu_baseline"] = {
                 "value": v, "unit": "bases/s", "cores": cores, "kind": "port",
@@ -537,7 +537,7 @@ def worker(args, rank, world, local_rank):
                 "same_segments_as_device": segf == res[:nf],
             }
             line["gpu_over_cpu_faithful"] = value / n_gpus / vf
-        if not args.no_legs:
+        if not args.no_legs and n_gpus == 1:
             # host->device copy inside the clock: dagcon_consensus on the warm context (pageable blobs),
             # then with the blobs in page-locked memory (dagcon_host_alloc)
             t1 = time.perf_counter()
