@@ -512,7 +512,7 @@ static int upload_impl(dagcon_ctx *ctx, const dagcon_batch *b, const void *dev_q
             // pieces a target can give: up to 256, one per 128 positions of the average backbone
             const uint64_t avail = std::min<uint64_t>(256, std::max<uint64_t>(1, c->sum_bb / T / 128));
             const uint64_t k = (uint64_t)T * avail / DQ_ROWS / slots;                     // whole rounds at that many pieces
-            if (k >= 1 || (uint64_t)T * avail / DQ_ROWS * 10u >= 9u * slots) {            // (or one round nine tenths full)
+            if (k >= 1 || (uint64_t)T * avail / DQ_ROWS * 10u >= 6u * slots) {            // (or one round six tenths full)
                 c->seg_max = (uint32_t)std::min<uint64_t>(avail, std::max<uint64_t>(k, 1) * slots * DQ_ROWS / T);
                 c->use_q = 1;
             }
