@@ -788,6 +788,15 @@ def test_align_kat_and_twin(gpu_ctx_factory, monkeypatch):
     assert ctx.align(pairs) == exp
     monkeypatch.setenv("DAGCON_ALIGN_ROWS", "5000")                 # several launch groups
     assert ctx.align(pairs) == exp
+    # the static bands alone (every kernel instance of k_align_band; by default the band that follows the
+    # alignment takes the long pairs and the static ones only see the short pairs and the fall-backs)
+    monkeypatch.delenv("DAGCON_ALIGN_ROWS")
+    monkeypatch.setenv("DAGCON_ALIGN_STATIC", "1")
+    monkeypatch.setenv("OG_NO_ADAPTIVE", "1")
+    exp_static = [oracle.banded_align(q, t) for q, t in pairs]
+    assert ctx.align(pairs) == exp_static
+    # (on these pairs the two agree wherever the following band stood)
+    assert sum(a != b for a, b in zip(exp, exp_static)) <= 2
 
 
 def test_cli_pre_input_with_align(tmp_path):
