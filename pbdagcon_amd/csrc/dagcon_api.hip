@@ -492,12 +492,12 @@ static int upload_impl(dagcon_ctx *ctx, const dagcon_batch *b, const void *dev_q
     c->gcuts = c->full_span ? 0u : 1u;
     if (const char *e = getenv("DAGCON_GCUTS")) c->gcuts = atoi(e) ? 1u : 0u;
     // merge workers per target: about one chip's worth of resident waves (8 per SIMD x 1024
-    // SIMDs) over the batch, never fewer than 8 nor more than 64 per target
+    // SIMDs) over the batch, never fewer than 8 nor more than 256 per target
     if (c->opts.max_segments) c->seg_max = c->opts.max_segments > 64u ? 64u : c->opts.max_segments;
     else if (c->seg_env) c->seg_max = c->seg_env;
     else if (c->gcuts) c->seg_max = 64;      // the worklist of k_cuts2 is taken by ticket: the finer its entries the better
                                              // the balance (config-5 shape, 1,000 targets: 8 / 32 / 64 pieces 54 / 34 / 31 ms)
-    else { uint32_t sm = T ? 8192u / T : 8u; c->seg_max = sm < 8u ? 8u : sm > 64u ? 64u : sm; }
+    else { uint32_t sm = T ? 8192u / T : 8u; c->seg_max = sm < 8u ? 8u : sm > 256u ? 256u : sm; }
     if (c->gcuts && !c->opts.min_segment_len) c->seg_min = 256;
     // k_merge_q (four segments per wave, DQ_WAVES waves per SIMD) for full-span batches big enough to fill the chip with
     // it: as many pieces as go (<= 256 per target) with its waves filling the chip a whole number of times -- a last round
