@@ -521,7 +521,8 @@ static int upload_impl(dagcon_ctx *ctx, const dagcon_batch *b, const void *dev_q
     if (c->use_q && !c->opts.min_segment_len) c->seg_min = 128;                     // (its pieces are a quarter of a wave's work)
     // bestPath is swept in three times as many pieces: its waves are light (one piece = one
     // sequential sweep when that is asked for)
-    c->bp_max = c->seg_max == 1 ? 1u : std::min(64u, 3u * c->seg_max);
+    // (more than 64 of them only where 64 per target leave the chip short of waves; never on the partial-span path)
+    c->bp_max = c->seg_max == 1 ? 1u : std::min(c->gcuts || T >= 256u ? 64u : (uint32_t)DG_BP_PIECES, 3u * c->seg_max);
     if (const char *e = getenv("DAGCON_BP_SEGS")) { const int v = atoi(e); if (v >= 1 && v <= 64) c->bp_max = (uint32_t)v; }
     // scratch per (target, piece): 4096 words where that is cheap, less for batches of very many
     // targets (2 GB in all at most; a piece that needs more raises DG_E_STACK: grown x4, re-run)

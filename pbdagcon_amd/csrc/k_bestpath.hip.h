@@ -113,6 +113,7 @@ struct DgWalkShared {
 // wherever on the backbone they lie, and its recursion their predecessors: edges from anywhere into that
 // little tree.  Its scores depend on nothing but exit, so k_bp_xtree has them first (final flag 2.0) and an
 // edge into it is an escape like an edge to exit itself: -inf for A, its absolute score for B and the rest.
+#define DG_BP_PIECES 256          // most pieces of a target's bestPath sweep (full-span path; 64 with p.gcuts)
 #define DG_BP_NINF (-1.0e9f)
 #define DG_BP_ONE 0xFFFFFFFFu      // DgParams::defer[0]: the target is swept in one piece; bp_end of the first piece: it ended at exit
 __device__ __forceinline__ void dg_bp_sweep(DgBpShared &S, const DgNode *nd, int32_t *best, float2 *score,
@@ -580,31 +581,36 @@ __global__ __launch_bounds__(64) void k_bp_join(DgParams p) {
     const uint64_t nb = p.node_base[t];
     const uint32_t *crow = p.cuts_bp + (uint64_t)t * (p.bp_max + 2u);     // (k_cuts, or k_cuts2 when p.gcuts)
     const uint32_t nseg = crow[0];
-    __shared__ uint32_t s_off[65], s_c0[64];
+    __shared__ uint32_t s_off[DG_BP_PIECES + 1], s_c0[DG_BP_PIECES];
     {
-        // where each segment's piece of the path goes (seg_max <= 64: one lane per segment)
-        uint32_t len = (uint32_t)lane < nseg ? p.bp_len[(uint64_t)t * p.bp_max + lane] : 0u;
-        if (p.gcuts) {
-            // the pieces that are on the path: the one from enter, which ends at cut number a (or at exit), then
-            // a, a + 1, ... up to the first one that ends at exit instead of at the next cut
-            const uint32_t e = (uint32_t)lane < nseg ? p.bp_end[(uint64_t)t * p.bp_max + lane] : 1u;
-            const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)e, 0);
-            const unsigned long long ends = __ballot((uint32_t)lane >= 1u && (uint32_t)lane < nseg && e == 0u);
-            bool on = lane == 0;
-            if (a != DG_BP_ONE && a < 64u && (ends >> a)) {
-                const uint32_t fe = a + (uint32_t)__ffsll((long long)(ends >> a)) - 1u;
-                on |= (uint32_t)lane >= a && (uint32_t)lane <= fe;
+        // where each segment's piece of the path goes: one lane per segment, 64 segments at a time
+        // (p.gcuts: at most 64 pieces, one round)
+        uint32_t carry = 0;
+        for (uint32_t s0 = 0; s0 < nseg || s0 == 0; s0 += 64) {
+            const uint32_t sg = s0 + (uint32_t)lane;
+            uint32_t len = sg < nseg ? p.bp_len[(uint64_t)t * p.bp_max + sg] : 0u;
+            if (p.gcuts) {
+                // the pieces that are on the path: the one from enter, which ends at cut number a (or at exit), then
+                // a, a + 1, ... up to the first one that ends at exit instead of at the next cut
+                const uint32_t e = (uint32_t)lane < nseg ? p.bp_end[(uint64_t)t * p.bp_max + lane] : 1u;
+                const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)e, 0);
+                const unsigned long long ends = __ballot((uint32_t)lane >= 1u && (uint32_t)lane < nseg && e == 0u);
+                bool on = lane == 0;
+                if (a != DG_BP_ONE && a < 64u && (ends >> a)) {
+                    const uint32_t fe = a + (uint32_t)__ffsll((long long)(ends >> a)) - 1u;
+                    on |= (uint32_t)lane >= a && (uint32_t)lane <= fe;
+                }
+                if (!on) len = 0;
             }
-            if (!on) len = 0;
+            uint32_t incl = len;
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t up = __shfl_up(incl, o); if (lane >= o) incl += up; }
+            if (sg < DG_BP_PIECES) { s_off[sg] = carry + incl - len; s_c0[sg] = sg < nseg ? crow[1 + sg] : 0u; }
+            carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
         }
-        uint32_t incl = len;
-        for (int o = 1; o < 64; o <<= 1) { const uint32_t up = __shfl_up(incl, o); if (lane >= o) incl += up; }
-        s_off[lane] = incl - len;
-        if (lane == 63) s_off[64] = incl;
-        s_c0[lane] = (uint32_t)lane < nseg ? crow[1 + lane] : 0u;
+        if (lane == 0) s_off[nseg < DG_BP_PIECES ? nseg : DG_BP_PIECES] = carry;
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-    const uint32_t total = s_off[64];
+    const uint32_t total = s_off[nseg < DG_BP_PIECES ? nseg : DG_BP_PIECES];
     const uint8_t *tmp = p.cns_tmp + nb;
     int32_t *segs = p.stk + (uint64_t)t * p.bp_max * p.stk_words;      // (range0, range1) pairs
     const uint32_t seg_cap = p.stk_words / 2;
@@ -613,7 +619,7 @@ __global__ __launch_bounds__(64) void k_bp_join(DgParams p) {
     bool met = false, ovf = false;
     uint32_t offs = 0, nout = 0, keep = 0;
     for (uint32_t s = 0; s < nseg; s++) {
-        const uint32_t len = s_off[s + 1 < 64 ? s + 1 : 64] - s_off[s], g0s = s_off[s];
+        const uint32_t len = s_off[s + 1] - s_off[s], g0s = s_off[s];
         const uint8_t *src = (p.gcuts && s == 0) ? p.cns_tmp0 + nb : tmp + s_c0[s];
         for (uint32_t j0 = 0; j0 < len; j0 += 64) {
             const uint32_t n = len - j0 < 64 ? len - j0 : 64;
@@ -663,7 +669,7 @@ __global__ __launch_bounds__(64) void k_bp_join(DgParams p) {
     if (co == ~0ull) return;
     uint8_t *out = p.cns + co;
     for (uint32_t s = 0; s < nseg; s++) {
-        const uint32_t g0s = s_off[s], len = s_off[s + 1 < 64 ? s + 1 : 64] - s_off[s];
+        const uint32_t g0s = s_off[s], len = s_off[s + 1] - s_off[s];
         const uint8_t *src = (p.gcuts && s == 0) ? p.cns_tmp0 + nb : tmp + s_c0[s];
         for (uint32_t j = lane; j < len && g0s + j < keep; j += 64) out[g0s + j] = (uint8_t)(src[j] & 0x7fu);
     }
