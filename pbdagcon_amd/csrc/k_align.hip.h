@@ -226,13 +226,13 @@ __global__ __launch_bounds__(64) void k_align_band(DgAlignParams p) {
         }
         // exclusive prefix minimum over the lanes in front
         int incl = lm, v;
-        v = dg_al_dpp<DG_DPP_ROW_SHR(1), 0xf>(DG_AL_BIG, incl); incl = v < incl ? v : incl;
-        v = dg_al_dpp<DG_DPP_ROW_SHR(2), 0xf>(DG_AL_BIG, incl); incl = v < incl ? v : incl;
-        v = dg_al_dpp<DG_DPP_ROW_SHR(4), 0xf>(DG_AL_BIG, incl); incl = v < incl ? v : incl;
-        v = dg_al_dpp<DG_DPP_ROW_SHR(8), 0xf>(DG_AL_BIG, incl); incl = v < incl ? v : incl;
-        v = dg_al_dpp<DG_DPP_BCAST15, 0xa>(DG_AL_BIG, incl); incl = v < incl ? v : incl;
-        v = dg_al_dpp<DG_DPP_BCAST31, 0xc>(DG_AL_BIG, incl); incl = v < incl ? v : incl;
-        int pm = dg_al_dpp<DG_DPP_WAVE_SHR1, 0xf>(DG_AL_BIG, incl);
+        v = dg_al_dpp<DG_DPP_ROW_SHR(1), 0xf>(0x7fffffff, incl); incl = v < incl ? v : incl;
+        v = dg_al_dpp<DG_DPP_ROW_SHR(2), 0xf>(0x7fffffff, incl); incl = v < incl ? v : incl;
+        v = dg_al_dpp<DG_DPP_ROW_SHR(4), 0xf>(0x7fffffff, incl); incl = v < incl ? v : incl;
+        v = dg_al_dpp<DG_DPP_ROW_SHR(8), 0xf>(0x7fffffff, incl); incl = v < incl ? v : incl;
+        v = dg_al_dpp<DG_DPP_BCAST15, 0xa>(0x7fffffff, incl); incl = v < incl ? v : incl;
+        v = dg_al_dpp<DG_DPP_BCAST31, 0xc>(0x7fffffff, incl); incl = v < incl ? v : incl;
+        int pm = dg_al_dpp<DG_DPP_WAVE_SHR1, 0xf>(0x7fffffff, incl);
         uint32_t word = 0;
 #pragma unroll
         for (int c = 0; c < C; c++) {
@@ -375,19 +375,19 @@ __global__ __launch_bounds__(64) void k_align_adapt(DgAlignParams p) {
     int lo = -W;                                            // column of the band's first cell
     bool lost = false;
     const int kb = lane * C;
-    for (uint32_t i = 0; i <= n; i++) {
-        uint32_t shift = 0;
-        if (i > 0) {
-            // where the previous row's best cell is (its first one)
+    uint32_t shift = 0;
+    // the band moves on to row i: where the previous row's best cell is (its first one) says how far
+    auto advance = [&](const uint32_t i) {
+        {
             int mn = P[0] < P[1] ? P[0] : P[1], v;
-            v = dg_al_dpp<DG_DPP_ROW_SHR(1), 0xf>(DG_AL_BIG, mn); mn = v < mn ? v : mn;
-            v = dg_al_dpp<DG_DPP_ROW_SHR(2), 0xf>(DG_AL_BIG, mn); mn = v < mn ? v : mn;
-            v = dg_al_dpp<DG_DPP_ROW_SHR(4), 0xf>(DG_AL_BIG, mn); mn = v < mn ? v : mn;
-            v = dg_al_dpp<DG_DPP_ROW_SHR(8), 0xf>(DG_AL_BIG, mn); mn = v < mn ? v : mn;
-            v = dg_al_dpp<DG_DPP_BCAST15, 0xa>(DG_AL_BIG, mn); mn = v < mn ? v : mn;
-            v = dg_al_dpp<DG_DPP_BCAST31, 0xc>(DG_AL_BIG, mn); mn = v < mn ? v : mn;
+            v = dg_al_dpp<DG_DPP_ROW_SHR(1), 0xf>(0x7fffffff, mn); mn = v < mn ? v : mn;
+            v = dg_al_dpp<DG_DPP_ROW_SHR(2), 0xf>(0x7fffffff, mn); mn = v < mn ? v : mn;
+            v = dg_al_dpp<DG_DPP_ROW_SHR(4), 0xf>(0x7fffffff, mn); mn = v < mn ? v : mn;
+            v = dg_al_dpp<DG_DPP_ROW_SHR(8), 0xf>(0x7fffffff, mn); mn = v < mn ? v : mn;
+            v = dg_al_dpp<DG_DPP_BCAST15, 0xa>(0x7fffffff, mn); mn = v < mn ? v : mn;
+            v = dg_al_dpp<DG_DPP_BCAST31, 0xc>(0x7fffffff, mn); mn = v < mn ? v : mn;
             const int best = __builtin_amdgcn_readlane(mn, 63);
-            if (best >= DG_AL_LIM) { lost = true; break; }
+            if (best >= DG_AL_LIM) { lost = true; return; }
             const unsigned long long b0 = __ballot(P[0] == best), b1 = __ballot(P[1] == best);
             const int k0 = b0 ? 2 * (__ffsll((long long)b0) - 1) : 1 << 20, k1 = b1 ? 2 * (__ffsll((long long)b1) - 1) + 1 : 1 << 20;
             const int am = (k0 < k1 ? k0 : k1) - off;
@@ -418,6 +418,10 @@ __global__ __launch_bounds__(64) void k_align_adapt(DgAlignParams p) {
             }
             qcn = (int)s_qw[i & 127u];
         }
+    };
+    // row i.  EDGE: the band hangs over an end of t on this row (columns < 0 or > m are not cells)
+    auto row = [&](const uint32_t i, auto first_row, auto edge_row) {
+        constexpr bool FIRST = decltype(first_row)::value, EDGE = decltype(edge_row)::value;
         const int left = dg_al_dpp<DG_DPP_WAVE_SHR1, 0xf>(DG_AL_BIG, P[C - 1]);
         int A[C];
         uint32_t dbits = 0;
@@ -425,9 +429,9 @@ __global__ __launch_bounds__(64) void k_align_adapt(DgAlignParams p) {
 #pragma unroll
         for (int c = 0; c < C; c++) {
             const int j = jl + c;
-            const bool valid = (uint32_t)j <= m && kb + c >= off;
+            const bool valid = (!EDGE || (uint32_t)j <= m) && kb + c >= off;
             int best;
-            if (i == 0) best = j == 0 ? 0 : DG_AL_BIG;
+            if constexpr (FIRST) best = j == 0 ? 0 : DG_AL_BIG;
             else {
                 const int dg = (c == 0 ? left : P[c - 1]) + (T[c] == qc ? DG_AL_MATCH : DG_AL_MISMATCH);
                 const int up = P[c] + DG_AL_INS;
@@ -441,18 +445,18 @@ __global__ __launch_bounds__(64) void k_align_adapt(DgAlignParams p) {
             lm = x < lm ? x : lm;
         }
         int incl = lm, v;
-        v = dg_al_dpp<DG_DPP_ROW_SHR(1), 0xf>(DG_AL_BIG, incl); incl = v < incl ? v : incl;
-        v = dg_al_dpp<DG_DPP_ROW_SHR(2), 0xf>(DG_AL_BIG, incl); incl = v < incl ? v : incl;
-        v = dg_al_dpp<DG_DPP_ROW_SHR(4), 0xf>(DG_AL_BIG, incl); incl = v < incl ? v : incl;
-        v = dg_al_dpp<DG_DPP_ROW_SHR(8), 0xf>(DG_AL_BIG, incl); incl = v < incl ? v : incl;
-        v = dg_al_dpp<DG_DPP_BCAST15, 0xa>(DG_AL_BIG, incl); incl = v < incl ? v : incl;
-        v = dg_al_dpp<DG_DPP_BCAST31, 0xc>(DG_AL_BIG, incl); incl = v < incl ? v : incl;
-        int pm = dg_al_dpp<DG_DPP_WAVE_SHR1, 0xf>(DG_AL_BIG, incl);
+        v = dg_al_dpp<DG_DPP_ROW_SHR(1), 0xf>(0x7fffffff, incl); incl = v < incl ? v : incl;
+        v = dg_al_dpp<DG_DPP_ROW_SHR(2), 0xf>(0x7fffffff, incl); incl = v < incl ? v : incl;
+        v = dg_al_dpp<DG_DPP_ROW_SHR(4), 0xf>(0x7fffffff, incl); incl = v < incl ? v : incl;
+        v = dg_al_dpp<DG_DPP_ROW_SHR(8), 0xf>(0x7fffffff, incl); incl = v < incl ? v : incl;
+        v = dg_al_dpp<DG_DPP_BCAST15, 0xa>(0x7fffffff, incl); incl = v < incl ? v : incl;
+        v = dg_al_dpp<DG_DPP_BCAST31, 0xc>(0x7fffffff, incl); incl = v < incl ? v : incl;
+        int pm = dg_al_dpp<DG_DPP_WAVE_SHR1, 0xf>(0x7fffffff, incl);
         uint32_t word = 0;
 #pragma unroll
         for (int c = 0; c < C; c++) {
             const int j = jl + c;
-            const bool valid = (uint32_t)j <= m && kb + c >= off;
+            const bool valid = (!EDGE || (uint32_t)j <= m) && kb + c >= off;
             const int x = A[c] - DG_AL_DEL * (kb + c);
             const bool del = j > 0 && pm < x;
             const int sc = del ? pm + DG_AL_DEL * (kb + c) : A[c];
@@ -463,6 +467,13 @@ __global__ __launch_bounds__(64) void k_align_adapt(DgAlignParams p) {
         }
         if (lane == 0) word = shift;                        // (its cells lie in front of the band)
         dirs[(uint64_t)i * 64ull + (uint64_t)lane] = (uint8_t)word;
+    };
+    row(0u, std::true_type{}, std::true_type{});
+    for (uint32_t i = 1; i <= n && !lost; i++) {
+        advance(i);
+        if (lost) break;
+        if (lo >= 0 && lo + B - 1 <= (int)m) row(i, std::false_type{}, std::false_type{});
+        else row(i, std::false_type{}, std::true_type{});
     }
     // (n, m) must be a reachable cell of the last row
     const int kend = (int)m - lo + off;
