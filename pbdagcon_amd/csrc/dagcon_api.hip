@@ -952,7 +952,7 @@ static int align_device(Ctx *c, uint32_t n, const uint64_t *q_off, const uint32_
         size_t mfree = 0, mtotal = 0;
         if (hipMemGetInfo(&mfree, &mtotal) == hipSuccess) {
             const uint64_t have = (uint64_t)mfree + (uint64_t)ddir.cap;      // (the buffer of the last call is ours to reuse)
-            budget_rows = std::min<uint64_t>(32ull << 30, std::max<uint64_t>(1ull << 30, have / 4)) / 256ull;
+            budget_rows = std::min<uint64_t>(16ull << 30, std::max<uint64_t>(1ull << 30, have / 4)) / 256ull;
         }
     }
     if (const char *e = getenv("DAGCON_ALIGN_GB")) { const long long v = atoll(e); if (v >= 1 && v <= 200) budget_rows = ((uint64_t)v << 30) / 256ull; }
@@ -976,6 +976,11 @@ static int align_device(Ctx *c, uint32_t n, const uint64_t *q_off, const uint32_
         for (uint32_t a = 0; a < n; a++) (dg_align_halfwidth_first(q_len[a], t_len[a]) > DG_AL_WA ? ad : rest).push_back(a);
         if (getenv("DAGCON_ALIGN_STATIC")) { rest.insert(rest.end(), ad.begin(), ad.end()); ad.clear(); }      // test knob
         std::stable_sort(ad.begin(), ad.end(), [&](uint32_t x, uint32_t y) { return q_len[x] > q_len[y]; });
+        // groups of equal size (a small last one would run at the latency of its longest pair)
+        uint64_t all_rows = 0;
+        for (uint32_t a : ad) all_rows += dg_align_rows_adapt(q_len[a], t_len[a]);
+        const uint64_t ngrp = std::max<uint64_t>(1, (all_rows + budget_rows - 1) / budget_rows);
+        const uint64_t grp_rows = std::min<uint64_t>(budget_rows, all_rows / ngrp + 1 + (all_rows / ngrp) / 64);
         size_t first = 0;
         while (first < ad.size()) {
             uint64_t rows = 0;
@@ -983,7 +988,7 @@ static int align_device(Ctx *c, uint32_t n, const uint64_t *q_off, const uint32_
             while (first + cnt < ad.size()) {
                 const uint32_t a = ad[first + cnt];
                 const uint64_t r = dg_align_rows_adapt(q_len[a], t_len[a]);
-                if (cnt && rows + r > budget_rows) break;
+                if (cnt && rows + r > grp_rows) break;
                 dir_off[a] = rows;
                 rows += r; cnt++;
             }
