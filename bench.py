@@ -168,27 +168,48 @@ def rehearse(args, rank, world):
     return 0
 
 
-# ------------------------------------------------------------------ streaming (N = 1 point of configs[3])
-def stream_core(ctxs, batches, B):
-    """B batches (round-robin over `batches`) through the two contexts `ctxs`: an uploader thread one batch ahead
-    of the thread that waits for results.  Returns (seconds, consensus bases, summed device ms, first results)."""
+# ------------------------------------------------------------------ streaming: configs[3]
+def raw_fasta(ids, raw):
+    """FASTA records (main.cpp:141-143) straight from a dagcon_results struct."""
+    import ctypes as C
+    blob = C.string_at(raw.seq_blob, raw.seq_bytes) if raw.seq_bytes else b""
+    out = []
+    for t in range(raw.n_targets):
+        tid = ids[t].encode()
+        for s in range(raw.seg_begin[t], raw.seg_begin[t + 1]):
+            o, n = raw.seq_off[s], raw.seq_len[s]
+            out.append(b">%s/%d_%d\n%s\n" % (tid, raw.range0[s], raw.range1[s], blob[o:o + n]))
+    return b"".join(out)
+
+
+def stream_core(ctxs, batches, B, on_result=None, sync=None):
+    """B batches (round-robin over `batches`, or batches(i) when it is callable) through the two contexts
+    `ctxs`: an uploader thread one batch ahead of the thread that waits for results.  on_result(i, raw)
+    sees every batch's dagcon_results before its context is handed back.  Returns (seconds, consensus
+    bases, summed device ms, first results)."""
     import threading
     import queue
     import torch
-    nd = len(batches)
+    get = batches if callable(batches) else (lambda i: batches[i % len(batches)])
     ready = [queue.Queue(), queue.Queue()]
     free = [threading.Semaphore(1), threading.Semaphore(1)]
+    err = []
 
     def uploader():
-        for i in range(B):
-            k = i & 1
-            free[k].acquire()
-            ctxs[k].upload(batches[i % nd])
-            ctxs[k].run()
-            ready[k].put(i)
+        try:
+            for i in range(B):
+                k = i & 1
+                free[k].acquire()
+                ctxs[k].upload(get(i))
+                ctxs[k].run()
+                ready[k].put(i)
+        except Exception as e:                     # hand the failure to the waiting thread
+            err.append(e)
+            for q in ready:
+                q.put(-1)
 
     th = threading.Thread(target=uploader)
-    torch.cuda.synchronize()
+    (sync or torch.cuda.synchronize)()
     t0 = time.perf_counter()
     th.start()
     bases = 0
@@ -196,60 +217,233 @@ def stream_core(ctxs, batches, B):
     first = None
     for i in range(B):
         k = i & 1
-        ready[k].get()
+        if ready[k].get() < 0:
+            th.join()
+            raise err[0]
         raw = ctxs[k].fetch_raw()
         tm = ctxs[k].timings()
         dev_ms += tm["ms_total"]
         bases += tm["consensus_bases"]
         if first is None:
             first = ctxs[k].results_to_py(raw)
+        if on_result is not None:
+            on_result(i, raw)
         free[k].release()
     th.join()
-    torch.cuda.synchronize()
+    (sync or torch.cuda.synchronize)()
     return time.perf_counter() - t0, bases, dev_ms, first
 
 
-def stream_batches(args):
-    """B batches of args.targets targets through one GPU: two contexts on two streams, an uploader
-    thread one batch ahead of the thread that waits for results, inputs in page-locked host memory
-    (dagcon_host_alloc) so the copy runs at link speed.  The batches come from `--stream-distinct`
-    distinct synthetic batches used round-robin (generating 100 x 0.9 GB on the host would time
-    the generator)."""
-    import threading
-    import queue
-    import torch
-    from pbdagcon_amd import capi, synth
-    torch.cuda.set_device(0)
+def stream_plan(total, per_batch, world, tlen, coverage):
+    """The global target space [0, total) cut into one contiguous shard per rank (shard_ranges: the reference's
+    N workers drain one queue of all targets, main.cpp:251-274; here the queue is dealt up front) and every shard
+    into batches of per_batch targets.  Returns [(lo, hi, [(first, n), ...])] per rank."""
+    import numpy as np
+    from pbdagcon_amd.shard import shard_ranges
+    plan = []
+    for lo, hi in shard_ranges(np.full(total, float(tlen) * coverage), world):
+        plan.append((lo, hi, [(f, min(per_batch, hi - f)) for f in range(lo, hi, per_batch)]))
+    return plan
+
+
+def target_ids(first, n, tlen):
+    return ["t%07d/0_%d" % (first + k, tlen) for k in range(n)]
+
+
+def fake_records(first, n, tlen):
+    return b"".join(b">t%07d/0_%d/0_%d\n%s\n" % (t, tlen, tlen, hashlib.md5(b"%d" % t).hexdigest().encode() * (1 + t % 3))
+                    for t in range(first, first + n))
+
+
+def stream_worker(args, rank, world, local_rank, quiet=False):
+    """configs[3] as specified: --targets-total targets (default --targets x --stream-batches per rank) over
+    `world` ranks.  Every rank takes its shard of the GLOBAL target space, streams it in batches of --targets
+    through two contexts on its own GPU (upload of one batch beside the kernels of the other, host->device
+    copy of every batch inside the clock), and every --gather-every batches the FASTA made so far is gathered
+    on rank 0 (RCCL when the group is nccl).  Rank 0 checks the gathered payload against the size and SHA-256
+    every rank kept of its own part.  Only the first --stream-distinct batches of a shard are generated
+    (100 x 0.9 GB of synthetic strings would time the generator); later batches re-use their strings under
+    their own target ids, and their sequences must come out identical to the batch they re-use.
+    Returns the line (rank 0) or None."""
+    import numpy as np
+    dist = None
+    rehearsal = args.rehearse
+    if not rehearsal:
+        import torch
+        if args.backend != "nccl":
+            local_rank = local_rank % max(torch.cuda.device_count(), 1)
+        torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.backend == "nccl" and not rehearsal:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
+    on_gpu_group = dist is not None and dist.get_backend() == "nccl"
+    red_dev = None
+    if dist is not None:
+        red_dev = torch.device("cuda", local_rank) if on_gpu_group else torch.device("cpu")
+    from pbdagcon_amd.shard import gather_fasta
     opts = dict(min_cov=6, min_len=500, trim=50)
-    B = args.stream_batches
+    total = args.targets_total or args.targets * args.stream_batches * world
+    plan = stream_plan(total, args.targets, world, args.tlen, args.coverage)
+    lo, hi, mine = plan[rank]
+    B = len(mine)
+    n_rounds = max(-(-len(p[2]) // args.gather_every) for p in plan)      # gathers every rank takes part in
     nd = max(1, min(args.stream_distinct, B))
     thr = min(16, len(os.sched_getaffinity(0)))
-    ctxs = [capi.Context(device=0, **opts) for _ in range(2)]
-    batches = []
-    for i in range(nd):
-        b = synth.make_batch(args.targets, args.tlen, args.coverage, seed=1000, first_target=i * args.targets, threads=thr)
-        batches.append(ctxs[0].pin_batch(b))
-    # warm both contexts (arena allocation, first-use growth)
-    for c in ctxs:
-        c.upload(batches[0]); c.run(); c.fetch()
-    dt, bases, dev_ms, first = stream_core(ctxs, batches, B)
-    text_bytes = sum(int(b.qstr.size) * 2 for b in batches) / nd * B
-    line = {
-        "metric": "consensus bases/sec (whole node)", "value": bases / dt, "unit": "bases/s", "n_gpus": 1,
-        "steps": B, "warmup": 1, "ms_per_step": dt / B * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-        "config": {"workload": f"configs[3] at N=1: {B} batches x {args.targets} targets x {args.tlen} bp x {args.coverage}x "
-                               f"streamed through one GPU ({nd} distinct batches round-robin), host->device copy of every "
-                               "batch INSIDE the clock, page-locked input blobs, two contexts in flight",
-                   "targets_total": B * args.targets},
-        "h2d_GBps": text_bytes / dt / 1e9,
-        "device_ms_per_batch": dev_ms / B,
-        "targets_per_s": B * args.targets / dt,
-    }
-    print(json.dumps(line), flush=True)
+
+    ctxs, distinct = [], []
+    if not rehearsal:
+        from pbdagcon_amd import capi, synth
+        ctxs = [capi.Context(device=local_rank, **opts) for _ in range(2)]
+        for j in range(nd):
+            f, n = mine[j]
+            distinct.append(ctxs[0].pin_batch(synth.make_batch(n, args.tlen, args.coverage, seed=1000, first_target=f, threads=thr)))
+        for c in ctxs:                              # warm both contexts (arena allocation, first-use growth)
+            c.upload(distinct[0]); c.run(); c.fetch()
+
+    def batch_of(i):
+        f, n = mine[i]
+        src = distinct[i % nd]
+        return src if n == src.n_targets else src.select(range(n))
+
+    parts = []                      # this rank's FASTA, one piece per batch
+    seq_digest = {}                 # digest of the sequences of a distinct batch (ids left out)
+    reuse_ok = [True]
+    keep_first = {}
+
+    def seqs_only(fa):
+        return hashlib.sha256(b"\n".join(l for l in fa.split(b"\n") if not l.startswith(b">"))).digest()
+
+    gathered_parts = [[] for _ in range(world)]
+    state = {"done": 0, "round": 0, "sent": 0}
+    my_hash = hashlib.sha256()
+    my_size = [0]
+
+    def gather_round():
+        payload = b"".join(parts[state["sent"]:])
+        state["sent"] = len(parts)
+        my_hash.update(payload)
+        my_size[0] += len(payload)
+        state["round"] += 1
+        if dist is None:
+            gathered_parts[0].append(payload)
+            return
+        out, sizes = gather_fasta(payload, dist, torch, local_rank if on_gpu_group else None, return_sizes=True)
+        if rank == 0:
+            pos = 0
+            for r, n in enumerate(sizes):
+                gathered_parts[r].append(out[pos:pos + n])
+                pos += n
+
+    def on_result(i, raw):
+        f, n = mine[i]
+        fa = raw_fasta(target_ids(f, n, args.tlen), raw)
+        parts.append(fa)
+        if n == distinct[i % nd].n_targets:
+            d = seqs_only(fa)
+            if i < nd:
+                seq_digest[i] = d
+                keep_first[i] = ctxs[0].results_to_py(raw) if args.stream_verify else None
+            elif seq_digest.get(i % nd) != d:
+                reuse_ok[0] = False
+        state["done"] += 1
+        if state["done"] % args.gather_every == 0:
+            gather_round()
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        if not rehearsal:
+            torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    bases, dev_ms = 0, 0.0
+    if rehearsal:
+        for i, (f, n) in enumerate(mine):
+            parts.append(fake_records(f, n, args.tlen))
+            state["done"] += 1
+            if state["done"] % args.gather_every == 0:
+                gather_round()
+    elif B:
+        _, bases, dev_ms, _ = stream_core(ctxs, batch_of, B, on_result)
+    while state["round"] < n_rounds:                 # the tail, and the rounds a shorter shard sits out with nothing to send
+        gather_round()
+    fence()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        bt = torch.tensor([bases, hi - lo], dtype=torch.int64, device=red_dev)
+        dist.all_reduce(bt)
+        bases_all, targets_all = int(bt[0].item()), int(bt[1].item())
+    else:
+        bases_all, targets_all = bases, hi - lo
+
+    # ---- outside the clock: parity of the distinct batches against the oracle, the gather against the digests ----
+    verified, n_verified = True, 0
+    if args.stream_verify and not rehearsal:
+        from util import oracle_batch
+        for j in range(nd):
+            k = distinct[j].n_targets if args.stream_verify < 0 else min(args.stream_verify, distinct[j].n_targets)
+            exp = oracle_batch(distinct[j].select(range(k)), **opts)
+            verified = verified and exp == keep_first[j][:k]
+            n_verified += k
+    gather_ok = None
+    if dist is not None:
+        flag = torch.tensor([1 if (verified and reuse_ok[0]) else 0, n_verified], dtype=torch.int64, device=red_dev)
+        mn, sm = flag.clone(), flag.clone()
+        dist.all_reduce(mn, op=dist.ReduceOp.MIN)
+        dist.all_reduce(sm)
+        all_ok, n_verified = bool(mn[0].item()), int(sm[1].item())
+        me = torch.frombuffer(bytearray(my_hash.digest() + my_size[0].to_bytes(8, "little")), dtype=torch.uint8).to(red_dev)
+        outs = [torch.zeros(40, dtype=torch.uint8, device=red_dev) for _ in range(world)]
+        dist.all_gather(outs, me)
+        claims = [bytes(x.cpu().numpy().tobytes()) for x in outs]
+    else:
+        all_ok = verified and reuse_ok[0]
+        claims = [my_hash.digest() + my_size[0].to_bytes(8, "little")]
+    line = None
+    if rank == 0:
+        whole = [b"".join(g) for g in gathered_parts]            # rank order = global target order (contiguous shards)
+        gather_ok = all(sha(w) == c[:32] and len(w) == int.from_bytes(c[32:], "little") for w, c in zip(whole, claims))
+        payload = b"".join(whole)
+        if rehearsal:
+            gather_ok = gather_ok and payload == fake_records(0, total, args.tlen)
+        records = payload.count(b">")
+        text_bytes = 0 if rehearsal else sum(int(b.qstr.size) * 2 for b in distinct) / nd * B
+        line = {
+            "metric": "consensus bases/sec (whole node)", "value": bases_all / dt, "unit": "bases/s", "n_gpus": world,
+            "steps": B, "warmup": 1, "ms_per_step": dt / max(B, 1) * 1e3, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": f"configs[3]: {total} targets x {args.tlen} bp x {args.coverage}x over {world} GPU(s): every rank "
+                                   f"streams its shard of the global target space in batches of {args.targets} through two contexts "
+                                   f"(the first {nd} batches of a shard are generated, later ones re-use their strings under their own ids), "
+                                   f"host->device copy of every batch INSIDE the clock, FASTA gathered on rank 0 every {args.gather_every} batches",
+                       "targets_total": total, "batches_rank0": B, "shards": [[p[0], p[1]] for p in plan]},
+            "targets_done": targets_all, "targets_per_s": targets_all / dt,
+            "h2d_GBps_rank0": text_bytes / dt / 1e9, "device_ms_per_batch_rank0": dev_ms / max(B, 1),
+            "fasta_bytes": len(payload), "fasta_records": records, "gather_rounds": n_rounds,
+            "fasta_gather_ok": bool(gather_ok), "bit_exact_vs_oracle": bool(all_ok) if args.stream_verify and not rehearsal else None,
+            "targets_verified": n_verified, "reused_batches_identical": bool(all_ok) if not rehearsal else None,
+            "backend": "none" if dist is None else dist.get_backend(),
+            "batch0_sha256": hashlib.sha256(parts[0]).hexdigest() if parts else None,
+        }
+        if rehearsal:
+            line["rehearse"] = True
+        if not quiet:
+            print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
     for c in ctxs:
         c.close()
-    return 0
+    return line
 
 
 # ------------------------------------------------------------------ legs outside the timed region
@@ -595,6 +789,16 @@ def worker(args, rank, world, local_rank):
                                                                       res[:args.e2e_targets]))
             if n_gpus == 1 and config1:
                 line["e2e_pre"] = e2e_pre_leg(64, 50000, 60, dict(min_cov=8, min_len=500, trim=50))
+            if n_gpus == 1:
+                # the N = 1 point of configs[3]: 12 batches of this workload's size streamed through two contexts,
+                # uploads inside the clock; batch 0 is the batch `value` was measured on
+                ctx.close()
+                a3 = argparse.Namespace(**vars(args))
+                a3.stream_batches, a3.stream_distinct, a3.targets_total, a3.gather_every = 12, 2, 0, 4
+                a3.stream_verify, a3.rehearse = 64, False
+                c3 = stream_worker(a3, 0, 1, local_rank, quiet=True)
+                c3["batch0_identical_to_value_run"] = c3.pop("batch0_sha256") == hashlib.sha256(my_fasta).hexdigest()
+                line["configs3_n1"] = c3
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
@@ -619,7 +823,13 @@ def main():
     ap.add_argument("--backend", default="nccl",
                     help="process-group backend; 'gloo' lets several ranks rehearse on one GPU")
     ap.add_argument("--stream-batches", type=int, default=0)
-    ap.add_argument("--stream-distinct", type=int, default=4)
+    ap.add_argument("--stream-distinct", type=int, default=4, help="batches of a shard that are really generated")
+    ap.add_argument("--targets-total", type=int, default=0,
+                    help="configs[3]: size of the GLOBAL target space shared out over the ranks (100000); "
+                         "default --targets x --stream-batches per rank")
+    ap.add_argument("--gather-every", type=int, default=4, help="batches per FASTA gather on rank 0 (a super-batch)")
+    ap.add_argument("--stream-verify", type=int, default=64,
+                    help="targets of every generated batch checked against the oracle (-1: all, 0: none)")
     ap.add_argument("--rehearse", action="store_true")
     args = ap.parse_args()
 
@@ -628,10 +838,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.stream_batches or args.targets_total:
+        if not args.stream_batches:
+            args.stream_batches = -(-args.targets_total // (args.targets * world))
+        stream_worker(args, rank, world, local_rank)
+        return 0
     if args.rehearse:
         return rehearse(args, rank, world)
-    if args.stream_batches:
-        return stream_batches(args)
     return worker(args, rank, world, local_rank)
 
 

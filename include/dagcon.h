@@ -259,6 +259,14 @@ int dagcon_debug_graph(dagcon_ctx *ctx, uint32_t target, dagcon_graph_dump *out)
  * run (in-kernel cycle stamps of target 0); all zero in the shipped build. */
 int dagcon_debug_counters(dagcon_ctx *ctx, unsigned long long *out8);
 
+/* Host arithmetic only (no device, no context): the pieces dagcon_upload would cut the merge and bestPath
+ * sweeps of a batch of this shape into -- out4 = {pieces per target (merge), shortest stretch worth a
+ * piece, 1 when the four-segments-per-wave merge kernel takes the batch, pieces per target (bestPath)}.
+ * sum_positions = sum over active targets of tlen + 2 rounded up to a multiple of 4.  Every launch grid
+ * derived from these is non-empty: pieces >= 1 for every input (tests/test_abi.py sweeps it). */
+int dagcon_debug_plan(uint32_t n_targets, uint64_t n_alignments, uint64_t sum_positions, uint32_t partial_span,
+                      uint32_t max_segments, uint32_t min_segment_len, uint32_t out4[4]);
+
 #ifdef __cplusplus
 }
 #endif

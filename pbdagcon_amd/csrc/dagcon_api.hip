@@ -31,6 +31,56 @@ struct DevBuf {
     size_t cap = 0;
 };
 
+// ---- how many pieces the merge / bestPath sweeps of a batch are cut into (host arithmetic only: exported as
+// dagcon_debug_plan so that a CPU test can sweep it; every grid size derived from it is > 0) ----
+struct DgPlanIn { uint32_t T; uint64_t n_alns, sum_bb; uint32_t gcuts, max_segments, min_segment_len, seg_env, merge_q; };
+struct DgPlan { uint32_t seg_max, seg_min, use_q, bp_max; };
+static DgPlan dg_plan_pieces(const DgPlanIn &in) {
+    DgPlan pl;
+    const uint32_t T = in.T;
+    // shortest stretch worth a worker: 768 positions when that already fills the chip, shorter (down to 192)
+    // for small batches, whose waves would otherwise be few and long
+    pl.seg_min = in.min_segment_len;
+    if (!pl.seg_min) pl.seg_min = (uint32_t)std::min<uint64_t>(768, std::max<uint64_t>(192, in.sum_bb / 8192));
+    // merge workers per target: about one chip's worth of resident waves (8 per SIMD x 1024
+    // SIMDs) over the batch, never fewer than 8 nor more than 256 per target
+    if (in.max_segments) pl.seg_max = in.max_segments > 64u ? 64u : in.max_segments;
+    else if (in.seg_env) pl.seg_max = in.seg_env;
+    else if (in.gcuts) pl.seg_max = 64;      // the worklist of k_cuts2 is taken by ticket: the finer its entries the better
+                                             // the balance (config-5 shape, 1,000 targets: 8 / 32 / 64 pieces 54 / 34 / 31 ms)
+    else { uint32_t sm = T ? 8192u / T : 8u; pl.seg_max = sm < 8u ? 8u : sm > 256u ? 256u : sm; }
+    if (in.gcuts && !in.min_segment_len) pl.seg_min = 256;
+    // k_merge_q (four segments per wave, DQ_WAVES waves per SIMD) for full-span batches big enough to fill the chip with
+    // it: as many pieces as go (<= 256 per target) with its waves filling the chip a whole number of times -- a last round
+    // that is a third full costs as much as a full one (configs[1]: 36 / 49 / 56 / 64 pieces 20.6 / 17.4 / 19.2 / 18.3 ms)
+    pl.use_q = 0;
+    if (in.merge_q && !in.gcuts && pl.seg_max != 1) {
+        const uint32_t slots = 1024u * DQ_WAVES;
+        if (in.max_segments || in.seg_env) pl.use_q = 1;                            // (the caller's number of pieces)
+        // a row holds 8 + 8 list entries in its one-look path and 16 in the generic one: past ~70 reads per target
+        // too many visits outgrow it (600 targets x 6 kb: 60x 8.9 ms against k_merge's 11.4, 100x 30.6 against 17.8)
+        else if (T && in.n_alns <= 72ull * T) {
+            // pieces a target can give: up to 256, one per 128 positions of the average backbone
+            const uint64_t avail = std::min<uint64_t>(256, std::max<uint64_t>(1, in.sum_bb / T / 128));
+            const uint64_t k = (uint64_t)T * avail / DQ_ROWS / slots;                     // whole rounds at that many pieces
+            if (k >= 1 || (uint64_t)T * avail / DQ_ROWS * 10u >= 6u * slots) {            // (or one round six tenths full)
+                // (very many short targets -- more targets than a round has rows: unless every target gets at
+                // least two pieces the wave-per-segment kernel keeps the batch)
+                const uint64_t sm = std::min<uint64_t>(avail, std::max<uint64_t>(k, 1) * slots * DQ_ROWS / T);
+                if (sm >= 2) { pl.seg_max = (uint32_t)sm; pl.use_q = 1; }
+            }
+        }
+    }
+    if (pl.seg_max < 1) pl.seg_max = 1;
+    if (pl.use_q && !in.min_segment_len) pl.seg_min = 128;                         // (its pieces are a quarter of a wave's work)
+    // bestPath is swept in three times as many pieces: its waves are light (one piece = one
+    // sequential sweep when that is asked for)
+    // (more than 64 of them only where 64 per target leave the chip short of waves; never on the partial-span path)
+    pl.bp_max = pl.seg_max == 1 ? 1u : std::min(in.gcuts || T >= 256u ? 64u : (uint32_t)DG_BP_PIECES, 3u * pl.seg_max);
+    if (pl.bp_max < 1) pl.bp_max = 1;
+    return pl;
+}
+
 struct Ctx {
     dagcon_opts opts;
     int device = 0;
@@ -487,42 +537,16 @@ static int upload_impl(dagcon_ctx *ctx, const dagcon_batch *b, const void *dev_q
     c->full_span = n_whole == (uint64_t)c->h_aln_len.size();
     // shortest stretch worth a worker: 768 positions when that already fills the chip, shorter (down to 192)
     // for small batches, whose waves would otherwise be few and long
-    c->seg_min = c->opts.min_segment_len;
-    if (!c->seg_min) c->seg_min = (uint32_t)std::min<uint64_t>(768, std::max<uint64_t>(192, c->sum_bb / 8192));
     c->gcuts = c->full_span ? 0u : 1u;
     if (const char *e = getenv("DAGCON_GCUTS")) c->gcuts = atoi(e) ? 1u : 0u;
-    // merge workers per target: about one chip's worth of resident waves (8 per SIMD x 1024
-    // SIMDs) over the batch, never fewer than 8 nor more than 256 per target
-    if (c->opts.max_segments) c->seg_max = c->opts.max_segments > 64u ? 64u : c->opts.max_segments;
-    else if (c->seg_env) c->seg_max = c->seg_env;
-    else if (c->gcuts) c->seg_max = 64;      // the worklist of k_cuts2 is taken by ticket: the finer its entries the better
-                                             // the balance (config-5 shape, 1,000 targets: 8 / 32 / 64 pieces 54 / 34 / 31 ms)
-    else { uint32_t sm = T ? 8192u / T : 8u; c->seg_max = sm < 8u ? 8u : sm > 256u ? 256u : sm; }
-    if (c->gcuts && !c->opts.min_segment_len) c->seg_min = 256;
-    // k_merge_q (four segments per wave, DQ_WAVES waves per SIMD) for full-span batches big enough to fill the chip with
-    // it: as many pieces as go (<= 256 per target) with its waves filling the chip a whole number of times -- a last round
-    // that is a third full costs as much as a full one (configs[1]: 36 / 49 / 56 / 64 pieces 20.6 / 17.4 / 19.2 / 18.3 ms)
-    c->use_q = 0;
-    if (c->merge_q && !c->gcuts && c->seg_max != 1) {
-        const uint32_t slots = 1024u * DQ_WAVES;
-        if (c->opts.max_segments || c->seg_env) c->use_q = 1;                       // (the caller's number of pieces)
-        // a row holds 8 + 8 list entries in its one-look path and 16 in the generic one: past ~70 reads per target
-        // too many visits outgrow it (600 targets x 6 kb: 60x 8.9 ms against k_merge's 11.4, 100x 30.6 against 17.8)
-        else if (T && c->h_aln_len.size() <= 72ull * T) {
-            // pieces a target can give: up to 256, one per 128 positions of the average backbone
-            const uint64_t avail = std::min<uint64_t>(256, std::max<uint64_t>(1, c->sum_bb / T / 128));
-            const uint64_t k = (uint64_t)T * avail / DQ_ROWS / slots;                     // whole rounds at that many pieces
-            if (k >= 1 || (uint64_t)T * avail / DQ_ROWS * 10u >= 6u * slots) {            // (or one round six tenths full)
-                c->seg_max = (uint32_t)std::min<uint64_t>(avail, std::max<uint64_t>(k, 1) * slots * DQ_ROWS / T);
-                c->use_q = 1;
-            }
-        }
+    {
+        DgPlanIn pi;
+        pi.T = T; pi.n_alns = c->h_aln_len.size(); pi.sum_bb = c->sum_bb; pi.gcuts = c->gcuts;
+        pi.max_segments = c->opts.max_segments; pi.min_segment_len = c->opts.min_segment_len;
+        pi.seg_env = c->seg_env; pi.merge_q = c->merge_q ? 1u : 0u;
+        const DgPlan pl = dg_plan_pieces(pi);
+        c->seg_max = pl.seg_max; c->seg_min = pl.seg_min; c->use_q = (int)pl.use_q; c->bp_max = pl.bp_max;
     }
-    if (c->use_q && !c->opts.min_segment_len) c->seg_min = 128;                     // (its pieces are a quarter of a wave's work)
-    // bestPath is swept in three times as many pieces: its waves are light (one piece = one
-    // sequential sweep when that is asked for)
-    // (more than 64 of them only where 64 per target leave the chip short of waves; never on the partial-span path)
-    c->bp_max = c->seg_max == 1 ? 1u : std::min(c->gcuts || T >= 256u ? 64u : (uint32_t)DG_BP_PIECES, 3u * c->seg_max);
     if (const char *e = getenv("DAGCON_BP_SEGS")) { const int v = atoi(e); if (v >= 1 && v <= 64) c->bp_max = (uint32_t)v; }
     // scratch per (target, piece): 4096 words where that is cheap, less for batches of very many
     // targets (2 GB in all at most; a piece that needs more raises DG_E_STACK: grown x4, re-run)
@@ -809,6 +833,18 @@ int dagcon_debug_counters(dagcon_ctx *ctx, unsigned long long *out8) {
     DgStatus st;
     HIPCHK(c, d2h(c, &st, c->d_st.p, sizeof st));
     for (int i = 0; i < 16; i++) out8[i] = st.dbg[i];
+    return DAGCON_OK;
+}
+
+// host arithmetic only (no device, no context): the pieces a batch of that shape would be cut into
+int dagcon_debug_plan(uint32_t n_targets, uint64_t n_alignments, uint64_t sum_positions, uint32_t partial_span,
+                      uint32_t max_segments, uint32_t min_segment_len, uint32_t out4[4]) {
+    if (!out4) return DAGCON_ERR_INVALID_ARG;
+    DgPlanIn pi;
+    pi.T = n_targets; pi.n_alns = n_alignments; pi.sum_bb = sum_positions; pi.gcuts = partial_span ? 1u : 0u;
+    pi.max_segments = max_segments; pi.min_segment_len = min_segment_len; pi.seg_env = 0; pi.merge_q = 1;
+    const DgPlan pl = dg_plan_pieces(pi);
+    out4[0] = pl.seg_max; out4[1] = pl.seg_min; out4[2] = pl.use_q; out4[3] = pl.bp_max;
     return DAGCON_OK;
 }
 

@@ -76,3 +76,34 @@ def test_product_does_not_import_oracle():
                 txt = open(os.path.join(dp, fn), errors="ignore").read()
                 assert "import oracle" not in txt and "from oracle" not in txt, fn
                 assert "dagcon_oracle" not in txt and "liboracle" not in txt, fn
+
+
+def test_piece_plan_never_gives_an_empty_grid():
+    """dagcon_upload's piece arithmetic (dagcon_debug_plan: host only).  A batch of very many short targets used to
+    come out with 0 merge pieces per target (T > 24576 with fewer than 256 positions each: grids of 0 blocks for
+    k_merge_q / k_bp_sweep / k_bp_walk); every shape must give 1 <= pieces <= 256, bestPath pieces >= 1, and the
+    four-segments-per-wave kernel only with at least two pieces per target."""
+    from pbdagcon_amd import capi
+    lib = capi.load()
+    lib.dagcon_debug_plan.argtypes = [ctypes.c_uint32, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32,
+                                      ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32 * 4]
+    out = (ctypes.c_uint32 * 4)()
+    Ts = sorted(set(list(range(1, 70)) + [96, 255, 256, 257, 1000, 4000, 8191, 8192, 8193, 24575, 24576, 24577,
+                                          30000, 50000, 65536, 100000]))
+    for T in Ts:
+        for per in (4, 40, 132, 256, 600, 1004, 10004, 50004):        # positions per target (tlen + 2, rounded)
+            for cov in (1, 8, 40, 72, 73, 300):
+                for partial in (0, 1):
+                    for ms in (0, 1, 3, 64, 500):
+                        assert lib.dagcon_debug_plan(T, T * cov, T * per, partial, ms, 0, out) == 0
+                        seg_max, seg_min, use_q, bp_max = list(out)
+                        assert 1 <= seg_max <= 256 and 1 <= bp_max <= 256 and seg_min >= 1, (T, per, cov, partial, ms, list(out))
+                        assert (T * seg_max + 3) // 4 > 0 and T * bp_max > 0
+                        if use_q and not ms:
+                            assert seg_max >= 2 and not partial, (T, per, cov, list(out))
+    # the shape the advice named: 24577 targets below 256 positions each -> not the row kernel with 0 pieces
+    lib.dagcon_debug_plan(24577, 24577 * 8, 24577 * 132, 0, 0, 0, out)
+    assert out[0] >= 1 and out[3] >= 1
+    # configs[1]: 1,000 x 10 kb x 40x keeps the choice the round-2 measurements were made with
+    lib.dagcon_debug_plan(1000, 40000, 1000 * 10004, 0, 0, 0, out)
+    assert list(out) == [73, 128, 1, 64]

@@ -735,6 +735,29 @@ def test_bench_two_ranks_share_the_gpu():
     assert line["targets_verified"] == 24 + 16
 
 
+def test_bench_streams_its_shard_in_batches_two_ranks():
+    """configs[3] as specified, rehearsed on the one GPU of the box: two gloo ranks, each streams ITS shard of the global
+    target space (3 batches of 24 targets) through two contexts, FASTA gathered per super-batch; every generated batch
+    is checked against the oracle target by target (--stream-verify -1), the re-used batch against the batch it
+    re-uses, the gathered payload against every rank's size + SHA-256."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo",
+                          "--stream-batches", "3", "--stream-distinct", "2", "--gather-every", "2", "--targets", "24",
+                          "--tlen", "2000", "--coverage", "16", "--stream-verify", "-1"],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["targets_total"] == 144 and line["targets_done"] == 144
+    assert line["fasta_gather_ok"] is True and line["bit_exact_vs_oracle"] is True and line["reused_batches_identical"] is True
+    assert line["targets_verified"] == 2 * 2 * 24 and line["fasta_records"] == 144 and line["gather_rounds"] == 2
+    assert line["value"] > 0
+
+
 # ---- the -a stage: .pre records re-aligned on the device (SURVEY 8f-2) ------------------------
 
 def _mutate(rng, t, sub=0.03, ins=0.08, dele=0.05):

@@ -193,6 +193,30 @@ def test_bench_gpus_flag_starts_the_ranks_itself():
     assert line["n_gpus"] == 2 and line["fasta_gather_ok"] is True and line["records"] == 22
 
 
+def test_bench_streams_the_global_target_space_over_ranks():
+    """configs[3] as specified (main.cpp:251-274: N workers drain ONE queue of all targets): `bench.py --gpus 3
+    --stream-batches 4` gives every rank its shard of the global target space, each streams it in batches and the
+    FASTA is gathered on rank 0 per super-batch; --rehearse fabricates the records (no device).  Also a total that
+    does not divide (ragged last batches, ranks with different batch counts)."""
+    import json
+    out = _bench("--gpus", "3", "--backend", "gloo", "--rehearse", "--stream-batches", "4", "--targets", "8",
+                 "--tlen", "300", "--coverage", "5", "--gather-every", "3")
+    assert out.returncode == 0, out.stdout + out.stderr
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 3 and line["fasta_gather_ok"] is True and line["backend"] == "gloo"
+    assert line["config"]["targets_total"] == 96 and line["fasta_records"] == 96 and line["targets_done"] == 96
+    assert line["config"]["shards"] == [[0, 32], [32, 64], [64, 96]] and line["gather_rounds"] == 2
+    out = _bench("--gpus", "3", "--backend", "gloo", "--rehearse", "--targets-total", "101", "--targets", "8",
+                 "--tlen", "300", "--coverage", "5")
+    assert out.returncode == 0, out.stdout + out.stderr
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["fasta_gather_ok"] is True and line["fasta_records"] == 101 and line["targets_done"] == 101
+    assert [b - a for a, b in line["config"]["shards"]] == [34, 34, 33]
+    out = _bench("--rehearse", "--stream-batches", "3", "--targets", "5")           # one rank: no process group
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out.returncode == 0 and line["fasta_gather_ok"] is True and line["fasta_records"] == 15
+
+
 def test_bench_without_a_gpu_fails_loudly():
     """The measured path has no CPU stand-in: without a device bench.py ends with an error."""
     import torch
