@@ -529,10 +529,32 @@ def e2e_pre_leg(n_targets, tlen, coverage, opts):
                 best = (dt, out.stdout)
         dt, fasta = best
         bases = sum(len(l) for l in fasta.split(b"\n") if l and not l.startswith(b">"))
+        # outside the clock: the first and the last target through the CPU twin of the aligner (SimpleAligner.cpp:25-63
+        # restated: parity unpinned beyond the reference's one KAT) + the oracle's consensus; their records must be in the
+        # FASTA byte for byte
+        import oracle
+        from concurrent.futures import ThreadPoolExecutor
+        checked, same = 0, True
+        for t in sorted({0, b.n_targets - 1}):
+            recs = b.target_alignments(t)
+
+            def one(rec):
+                start, q, tt = rec
+                ts = tt.replace(b"-", b"")
+                st, en, qa, ta = oracle.simple_align(start - 1, int(b.tlen[t]), b"+", q.replace(b"-", b""), ts)
+                return (st, qa, ta)
+
+            with ThreadPoolExecutor(max_workers=min(16, len(os.sched_getaffinity(0)))) as ex:
+                alns = list(ex.map(one, recs))
+            exp = b"".join(b">%s/%d_%d\n%s\n" % (b.ids[t].encode(), r0, r1, sq) for r0, r1, sq in
+                           oracle.consensus_target(int(b.tlen[t]), alns, opts["min_len"], opts["trim"], opts["min_cov"]))
+            same = same and len(exp) > 0 and exp in fasta
+            checked += 1
         return {"value": bases / dt, "unit": "bases/s", "targets": n_targets, "tlen": tlen, "coverage": coverage, "wall_s": dt,
-                "text_GBps": size / dt / 1e9, "pre_bytes": size,
+                "text_GBps": size / dt / 1e9, "pre_bytes": size, "fasta_checked": checked, "fasta_identical_to_twin_and_oracle": bool(same),
                 "what": "pbdagcon_amd/bin/pbdagcon -a <file.pre on tmpfs> -> FASTA (config-3 shape), process start, parse, "
-                        "re-alignment of every record, consensus, formatting all inside the clock; best of 2"}
+                        "re-alignment of every record, consensus, formatting all inside the clock; best of 2; two targets "
+                        "re-done on the CPU (twin aligner + oracle) outside the clock"}
     finally:
         try:
             os.unlink(path)

@@ -19,7 +19,9 @@
 #include "dagcon_dev.h"
 #include "k_build.hip.h"
 #include "k_merge.hip.h"
-#include "k_merge_tile.hip.h"
+#ifdef DG_EXPERIMENTS
+#include "experiments/k_merge_tile.hip.h"     // dropped experiments: `make experiments` only, never in the shipped library
+#endif
 #include "k_merge_q.hip.h"
 #include "k_bestpath.hip.h"
 #include "k_align.hip.h"
@@ -33,6 +35,7 @@ struct DevBuf {
 
 // ---- how many pieces the merge / bestPath sweeps of a batch are cut into (host arithmetic only: exported as
 // dagcon_debug_plan so that a CPU test can sweep it; every grid size derived from it is > 0) ----
+#define DQ_KMAX 72u      // reads per target up to which the row sweep (k_merge_q) beats the wave sweep (k_merge)
 struct DgPlanIn { uint32_t T; uint64_t n_alns, sum_bb; uint32_t gcuts, max_segments, min_segment_len, seg_env, merge_q; };
 struct DgPlan { uint32_t seg_max, seg_min, use_q, bp_max; };
 static DgPlan dg_plan_pieces(const DgPlanIn &in) {
@@ -59,7 +62,7 @@ static DgPlan dg_plan_pieces(const DgPlanIn &in) {
         if (in.max_segments || in.seg_env) pl.use_q = 1;                            // (the caller's number of pieces)
         // a row holds 8 + 8 list entries in its one-look path and 16 in the generic one: past ~70 reads per target
         // too many visits outgrow it (600 targets x 6 kb: 60x 8.9 ms against k_merge's 11.4, 100x 30.6 against 17.8)
-        else if (T && in.n_alns <= 72ull * T) {
+        else if (T && in.n_alns <= (uint64_t)DQ_KMAX * T) {
             // pieces a target can give: up to 256, one per 128 positions of the average backbone
             const uint64_t avail = std::min<uint64_t>(256, std::max<uint64_t>(1, in.sum_bb / T / 128));
             const uint64_t k = (uint64_t)T * avail / DQ_ROWS / slots;                     // whole rounds at that many pieces
@@ -91,6 +94,7 @@ struct Ctx {
 
     // host copy of the filtered batch
     uint32_t T = 0, A = 0;
+    int fold = 1;                                  // duplicate insertion chains folded by k_emit (DAGCON_FOLD=0: never)
     int merge_q = 1, use_q = 0;                    // k_merge_q: four segments per wave (DAGCON_MERGE_Q=0: never); this batch
     uint32_t max_k = 0, max_tlen = 0;
     uint64_t sum_len = 0, sum_bb = 0, mat_cells = 0, blob_bytes = 0;
@@ -284,7 +288,13 @@ void fill_params(Ctx *c, DgParams &p) {
     p.stk = (int32_t *)c->d_stk.p; p.stk_words = c->stk_words; p.growth_pct = c->growth_pct;
     // the prefetch wave pays while the chip has idle wave slots; past ~1.5 workers per SIMD the
     // workers hide each other's latency and it only takes issue slots from them
+#ifdef DG_EXPERIMENTS
     { const char *e = getenv("DAGCON_PF_AHEAD"); p.pf_ahead = e ? (uint32_t)atoi(e) : (c->expected_workers >= 4096 ? 0u : 48u); }
+#else
+    p.pf_ahead = 0;
+#endif
+    p.fold = (c->fold && !(c->opts.flags & DAGCON_FLAG_STOP_AFTER_BUILD)) ? 1u : 0u;
+    p.q_kmax = c->use_q && !c->opts.max_segments && !c->seg_env && c->max_k > DQ_KMAX ? DQ_KMAX : 0u;
     p.seg_max = c->seg_max; p.seg_min = c->seg_min; p.cuts = (uint32_t *)c->d_cuts.p; p.bp_max = c->bp_max; p.cuts_bp = (uint32_t *)c->d_cuts_bp.p; p.bp_stat = (float *)c->d_bp_stat.p; p.bp_len = (uint32_t *)c->d_bp_len.p;
     p.gcuts = c->gcuts; p.sh_log = c->sh_log;
     p.rd_s = (uint32_t *)c->d_rd.p; p.rd_e = p.rd_s + c->A; p.rd_lead = p.rd_e + c->A; p.rd_trail = p.rd_lead + c->A;
@@ -354,14 +364,21 @@ int launch_all(Ctx *c) {
             hipLaunchKernelGGL(k_cuts2, dim3(c->T), dim3(64), 0, s, p);
             hipLaunchKernelGGL(k_merge_list, dim3(c->list_grid), dim3(64), 0, s, p);
             hipLaunchKernelGGL(k_merge_fin, dim3(c->T), dim3(64), 0, s, p);
-        } else if (c->tile_pos) {
+        }
+#ifdef DG_EXPERIMENTS
+        else if (c->tile_pos) {
             HIPCHK(c, hipMemsetAsync(c->d_tile_list.p, 0, 16, s));
             HIPCHK(c, hipFuncSetAttribute((const void *)k_merge_tile, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(c->tile_words * 4)));
             hipLaunchKernelGGL(k_cutmap, dim3(c->T), dim3(1024), 0, s, p);
             hipLaunchKernelGGL(k_merge_tile, dim3(c->T, c->tile_ny), dim3(DG_T_LANES), c->tile_words * 4, s, p);
             hipLaunchKernelGGL(k_merge_list, dim3(c->list_grid), dim3(64), 0, s, p);
         } else if (p.pf_ahead) hipLaunchKernelGGL(k_merge<true>, dim3(c->T * c->seg_max), dim3(128), 0, s, p);
-        else if (c->use_q) hipLaunchKernelGGL(k_merge_q, dim3((c->T * c->seg_max + DQ_ROWS - 1u) / DQ_ROWS), dim3(64), 0, s, p);
+#endif
+        else if (c->use_q) {
+            hipLaunchKernelGGL(k_merge_q, dim3((c->T * c->seg_max + DQ_ROWS - 1u) / DQ_ROWS), dim3(64), 0, s, p);
+            // (the few deep targets of a shallow batch: the same cuts, a wave per segment)
+            if (p.q_kmax) hipLaunchKernelGGL(k_merge<false>, dim3(c->T * c->seg_max), dim3(64), 0, s, p);
+        }
         else hipLaunchKernelGGL(k_merge<false>, dim3(c->T * c->seg_max), dim3(64), 0, s, p);
     }
     HIPCHK(c, hipEventRecord(c->ev[3], s));
@@ -428,6 +445,7 @@ int dagcon_create(const dagcon_opts *opts, dagcon_ctx **out) {
         const int v = atoi(e);
         if (v >= 1 && v <= 64) c->seg_env = (uint32_t)v;
     }
+    if (const char *e = getenv("DAGCON_FOLD")) c->fold = atoi(e) != 0;
     if (const char *e = getenv("DAGCON_MERGE_Q")) c->merge_q = atoi(e) != 0;     // four segments per wave (k_merge_q.hip.h)
     memset(&c->tm, 0, sizeof c->tm);
     memset(&c->h_st, 0, sizeof c->h_st);
@@ -557,6 +575,7 @@ static int upload_impl(dagcon_ctx *ctx, const dagcon_batch *b, const void *dev_q
         if (c->stk_words < base || (uint64_t)c->stk_words * pieces > (1024ull << 20)) c->stk_words = base;
     }
     if (c->gcuts) c->tile_list_cap = std::max<uint32_t>(c->tile_list_cap, (uint32_t)std::min<uint64_t>((uint64_t)T * c->seg_max + 64, 0x0FFFFFFFull));
+#ifdef DG_EXPERIMENTS
     // LDS tiles for mergeNodes: positions per tile from the LDS budget and the expected size of a
     // position's share of the graph (exact after the first run of a shape)
     {
@@ -579,6 +598,7 @@ static int upload_impl(dagcon_ctx *ctx, const dagcon_batch *b, const void *dev_q
             c->tile_list_cap = std::max<uint32_t>(c->tile_list_cap, (uint32_t)std::min<uint64_t>((uint64_t)T * c->tile_ny + 16, 0x0FFFFFFFull));
         }
     }
+#endif
     c->h_aln_begin[T] = c->h_aln_len.size();
     if (c->h_aln_len.size() > 0xFFFFFFF0ull) return fail(c, DAGCON_ERR_UNSUPPORTED, "too many alignments");
     c->A = (uint32_t)c->h_aln_len.size();

@@ -77,7 +77,9 @@ struct __attribute__((aligned(16))) DgNode {
 #define DG_NF_DEFER    8u   // bestPath on partial-span pileups: scored by k_bp_defer, after the segments' sweeps
 #define DG_NF_SHARED   4u   // during k_merge_list: a list of this vertex is shared by the segments' workers (DgGraph::sh)
 
-// arrival cell: (target base << 25) | (source id + 1); deletion: id field all ones
+// arrival cell: (target base << 25) | (source id + 1); deletion: id field all ones; DG_CELL_DUP (k_build.hip.h): a match
+// whose in-edge an earlier read's folded chain already brings
+// departure cell: (target id + 1) | (reads folded into this one's chain << 25)
 #define DG_CELL_ID(c)   ((c) & 0x1FFFFFFu)
 #define DG_CELL_DEL     0x1FFFFFFu
 #define DG_CELL_BASE(c) ((uint8_t)((c) >> 25))
@@ -161,6 +163,9 @@ struct DgParams {
     uint32_t stk_words;
     uint32_t growth_pct;           // pool growth region as % of the initial adjacency words
     uint32_t pf_ahead;             // vertices the prefetch wave runs ahead of the sweep (0 = off)
+    uint32_t fold;                 // 1: k_emit folds duplicate insertion chains as it builds (dg_emit_fold); 0 with
+                                   // DAGCON_FLAG_STOP_AFTER_BUILD (the dump is then addAln's graph itself) and DAGCON_FOLD=0
+    uint32_t q_kmax;               // k_merge_q takes the targets of at most this many reads, k_merge the deeper ones (0: no split)
     uint32_t seg_max;              // most segments a target's merge sweep is split into (k_cuts)
     uint32_t seg_min;              // shortest backbone stretch worth a worker of its own
     uint32_t *cuts;                // [T][seg_max + 2]: segment count, first vertex of each segment

@@ -788,6 +788,59 @@ __global__ __launch_bounds__(1024) void k_gscan(DgParams p) {
 // position.  Columns come 8 at a time (16-byte loads) into two 64-bit registers,
 // the backbone ids of the batch in four 16-byte loads.
 // ---------------------------------------------------------------------------
+// ---- duplicates folded while the graph is built (DgParams::fold) -------------------------------------------------
+// Two reads that leave the same backbone vertex u, insert the SAME bases and match the same next backbone position
+// v are merged by the reference when it visits u and the vertices of the first read's chain (mergeOutNodes groups
+// u's children by base, AlnGraphBoost.cpp:217-267): the later read's chain folds into the earlier one's vertex by
+// vertex and contributes nothing but counts -- at every level its vertex is a victim of the earlier read's, its out-edge
+// goes where the survivor's own already goes, its entries in out[u] and in[v] are erased with the others keeping their
+// order.  So the result of the sweep is the same when the later chain is never linked in (its vertices born deleted) and
+// its weights and edge counts are added to the earlier chain's at once (checked against the literal Python model on
+// thousands of adversarial pileups before any of it ran here; tests: the merged graph vertex by vertex with the fold on
+// and off).  About 55 % of all vertices mergeNodes reaps at configs[1] go this way, and 40 % of its merge visits.
+//
+// k_emit sees such a pair at one place: the lanes walk the backbone in lock step, and a chain that hangs between a
+// backbone vertex and the match column of position `pos` (insertion columns in front of pos only) is complete when the
+// lanes have done position pos.  Lanes of `em` hold: key (up to four inserted bases), anc (the vertex in front),
+// first (id of the chain's first vertex), nins.  Returns true for a lane whose chain is folded into an earlier lane's
+// (its arrival cell then becomes DG_CELL_DUP: the column counts as a match, the read brings no in-edge).
+#define DG_CELL_DUP 0x1FFFFFEu
+__device__ __forceinline__ bool dg_emit_fold(unsigned long long em, const bool elig, const uint32_t key, const uint32_t anc,
+                                          const uint32_t first, const uint32_t nins, const uint32_t pos, DgNode *ndt,
+                                          uint32_t *pool, uint32_t *dcell, const int lane) {
+    bool victim = false;
+    while (em) {
+        const int f = __ffsll((long long)em) - 1;
+        const uint32_t kf = (uint32_t)__builtin_amdgcn_readlane((int)key, f), af = (uint32_t)__builtin_amdgcn_readlane((int)anc, f);
+        const unsigned long long same = __ballot(elig && key == kf && anc == af);
+        em &= ~same;
+        const uint32_t n = (uint32_t)__popcll(same);
+        if (n < 2) {
+            if (!(em & (em - 1ull))) break;               // one chain left: nothing to pair it with
+            continue;
+        }
+        if (!((same >> lane) & 1ull)) continue;
+        if (lane == f) {
+            // the survivor: every vertex of the chain weighs n, every edge along it counts n (u's out-entry for its
+            // first vertex gets its count from the departure cell: k_lists)
+            for (uint32_t k = 0; k < nins; k++) {
+                const uint32_t id = first + k, rk = id - pos;
+                reinterpret_cast<DgNode *>(reinterpret_cast<char *>(ndt) + (id << 5))->weight = (int32_t)n;
+                pool[3u * rk + 1u] = n;
+            }
+            *dcell = (first + 1u) | ((n - 1u) << 25);
+        } else {
+            victim = true;
+            for (uint32_t k = 0; k < nins; k++) {
+                DgNode *nd = reinterpret_cast<DgNode *>(reinterpret_cast<char *>(ndt) + ((first + k) << 5));
+                nd->out_len = 0; nd->in_len = 0; nd->flags = DG_NF_DELETED;      // AlnGraphBoost.cpp:269-273
+            }
+            *dcell = 0u;
+        }
+    }
+    return victim;
+}
+
 #ifndef DG_EB
 #define DG_EB 16
 #endif
@@ -938,18 +991,23 @@ __global__ __launch_bounds__(64) void k_emit(DgParams p) {
 #pragma unroll
         for (int j = 0; j < DG_EB; j++) {
             const uint32_t pos = pos0 + j;
+            bool f_elig = false;
+            uint32_t f_anc = 0, f_apos = 0, f_key = 0, f_n = 0, f_first = 0;
             if (!done && bbpos == pos && pos < P1) {
                 // columns in front of this position that do not advance the backbone cursor:
                 // insertions (AlnGraphBoost.cpp:95-104); raw columns that match no branch are skipped
                 uint32_t ins_id = 0;
                 bool ins_open = false, have = false;
                 uint16_t c = 0;
+                f_anc = prev; f_apos = prev_pos; f_key = 0; f_n = 0;
+                const bool f_anc_ok = prev_bb && own;
                 while (i < hi) {
                     DG_COLUMN(i, c);
                     const uint8_t qb = DG_Q(c), tb = DG_T(c);
                     if (qb == tb || qb == DG_GAP) { have = true; break; }
                     if (tb == DG_GAP) {
-                        if (!ins_open) { ins_open = true; ins_id = gbv[j] + cmv[j]; }
+                        if (!ins_open) { ins_open = true; ins_id = gbv[j] + cmv[j]; f_first = ins_id; }
+                        f_key = (f_key << 8) | qb; f_n++;
                         const uint32_t id = ins_id++;
                         const uint32_t rk = id - bbpos;   // bbpos backbone vertices precede group bbpos
                         DgNode nd;
@@ -976,6 +1034,7 @@ __global__ __launch_bounds__(64) void k_emit(DgParams p) {
                     if (qb == tb) {                       // match (:75-85)
                         const uint32_t cur = bidv[j];
                         acell[j] = ((uint32_t)tb << 25) | (prev + 1u);
+                        f_elig = f_anc_ok && f_n >= 1u && f_n <= 4u;
                         DG_DEPART(cur);
                         prev = cur; prev_pos = bbpos; prev_bb = true; own = true;
                     } else {                              // deletion (:87-93)
@@ -983,6 +1042,15 @@ __global__ __launch_bounds__(64) void k_emit(DgParams p) {
                     }
                     bbpos++;
                     i++;
+                }
+            }
+            if (p.fold) {
+                // chains that closed at this position, two or more of them: fold the duplicates (dg_emit_fold)
+                const unsigned long long em = __ballot(f_elig);
+                if (__popcll(em) >= 2) {
+                    uint32_t *dcell = f_apos >= pos0 ? &s_D[(f_apos - pos0) * 64 + lane] : &DG_ECELL(Dm, f_apos);
+                    if (dg_emit_fold(em, f_elig, f_key, f_anc, f_first, f_n, pos, ndt, pool, dcell, lane))
+                        acell[j] = (acell[j] & 0xFE000000u) | DG_CELL_DUP;
                 }
             }
         }
@@ -1093,7 +1161,9 @@ __global__ __launch_bounds__(256) void k_lists(DgParams p) {
             // the enter) are grouped by peeling.  Entries go straight to the pool in the order of
             // their first read. ----
             const uint32_t cell = (uint32_t)lane < K ? row[lane] : 0u;
-            int32_t val = (int32_t)cell;                       // neighbour id + 1, 0 = none
+            // departure: neighbour id + 1 (0 = none) and, above bit 25, the reads k_emit folded into this one's chain
+            int32_t val = (int32_t)DG_CELL_ID(cell);
+            const int32_t extra = (int32_t)(cell >> 25);
             if (dir == 1) {
                 const uint32_t idf = DG_CELL_ID(cell);
                 const unsigned long long covered = __ballot(cell != 0u);
@@ -1102,7 +1172,7 @@ __global__ __launch_bounds__(256) void k_lists(DgParams p) {
                     n_match += (uint32_t)__popcll(__ballot(cell != 0u && idf != DG_CELL_DEL));
                     if (covered) last_base = DG_CELL_BASE((uint32_t)__builtin_amdgcn_readlane((int)cell, 63 - __clzll((long long)covered)));
                 }
-                val = (cell != 0u && idf != DG_CELL_DEL) ? (int32_t)idf : 0;
+                val = (cell != 0u && idf != DG_CELL_DEL && idf != DG_CELL_DUP) ? (int32_t)idf : 0;
             }
             const uint32_t gp = dir == 0 ? pos + 1 : pos;
             const int32_t chain = (int32_t)p.bid[bv + (dir == 0 ? pos + 1 : pos - 1)] + 1;
@@ -1110,14 +1180,14 @@ __global__ __launch_bounds__(256) void k_lists(DgParams p) {
             const unsigned long long cm = __ballot(val == chain);
             const bool uniq = val >= ulo && val < uhi;
             unsigned long long firsts = __ballot(uniq);
-            int32_t cnt = 1;
+            int32_t cnt = dir == 0 ? 1 + extra : 1;
             unsigned long long rem = __ballot(val != 0 && !uniq) & ~cm;
             while (rem) {
                 const int first = __ffsll((long long)rem) - 1;
                 const int32_t x = __builtin_amdgcn_readlane(val, first);
                 const unsigned long long same = __ballot(val == x);
                 rem &= ~same;
-                if (lane == first) cnt = __popcll(same);
+                if (lane == first) cnt = __popcll(same) + (dir == 0 ? extra : 0);
                 firsts |= 1ull << first;
             }
             const uint32_t n = 1u + (uint32_t)__popcll(firsts);
@@ -1149,7 +1219,8 @@ __global__ __launch_bounds__(256) void k_lists(DgParams p) {
         for (uint32_t r0 = 0; r0 < K; r0 += DG_WAVE) {
             const uint32_t r = r0 + lane;
             const uint32_t cell = r < K ? row[r] : 0u;
-            int32_t val = (int32_t)cell;                       // neighbour id + 1, 0 = none
+            int32_t val = (int32_t)DG_CELL_ID(cell);           // neighbour id + 1, 0 = none
+            const int32_t extra = dir == 0 ? (int32_t)(cell >> 25) : 0;       // reads folded into this one's chain (k_emit)
             if (dir == 1) {
                 const uint32_t idf = DG_CELL_ID(cell);
                 const unsigned long long covered = __ballot(cell != 0u);
@@ -1158,7 +1229,7 @@ __global__ __launch_bounds__(256) void k_lists(DgParams p) {
                     n_match += (uint32_t)__popcll(__ballot(cell != 0u && idf != DG_CELL_DEL));
                     if (covered) last_base = DG_CELL_BASE((uint32_t)__builtin_amdgcn_readlane((int)cell, 63 - __clzll((long long)covered)));
                 }
-                val = (cell != 0u && idf != DG_CELL_DEL) ? (int32_t)idf : 0;
+                val = (cell != 0u && idf != DG_CELL_DEL && idf != DG_CELL_DUP) ? (int32_t)idf : 0;
             }
             unsigned long long rem = __ballot(val != 0);
             if (!in_lds) {
@@ -1173,7 +1244,7 @@ __global__ __launch_bounds__(256) void k_lists(DgParams p) {
                 const int32_t x = __builtin_amdgcn_readlane(val, first);
                 const unsigned long long same = __ballot(val == x);
                 rem &= ~same;
-                const int c = __popcll(same);
+                const int c = __popcll(same) + __builtin_amdgcn_readlane(extra, first);
                 if (!in_lds) {
                     const unsigned long long hit = __ballot(lane < n && lv == x - 1);
                     if (hit) {

@@ -1174,6 +1174,8 @@ template <bool PF>
 __global__ __launch_bounds__(PF ? 128 : 64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_merge(DgParams p) {
     const uint32_t t = blockIdx.x / p.seg_max, seg = blockIdx.x % p.seg_max;
     if (dg_failed(p) || dg_tskip(p, t)) return;
+    // (a batch that k_merge_q sweeps leaves its deep targets to this kernel: DgParams::q_kmax)
+    if (p.q_kmax && (uint32_t)(p.aln_begin[t + 1] - p.aln_begin[t]) <= p.q_kmax) return;
     const uint32_t *crow = p.cuts + (uint64_t)t * (p.seg_max + 2u);
     const uint32_t nseg = crow[0];
     if (seg >= nseg) return;

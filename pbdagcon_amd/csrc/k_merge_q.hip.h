@@ -324,8 +324,6 @@ __device__ inline bool dq_merge_in_group(DgGraph &g, int n, uint32_t n_in_off, q
 
 // One segment [c_start, c_end] of target t, swept by the calling ROW (dg_merge_segment, mode DG_MM_WORKER, no
 // shared lists).  c_end = 0x7fffffff: the segment runs to the exit vertex.
-// One segment [c_start, c_end] of target t, swept by the calling ROW (dg_merge_segment, mode DG_MM_WORKER, no
-// shared lists).  c_end = 0x7fffffff: the segment runs to the exit vertex.
 __device__ __forceinline__ void dq_merge_segment(const DgParams &p, const uint32_t t, const int c_start, const int c_end,
                                                  int32_t *stk_base, int *s_stk, int *s_ring) {
     const int lane = threadIdx.x & (DQ_W - 1);
@@ -519,6 +517,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DQ_WAVES, DQ
     const uint32_t t = pair / p.seg_max, seg = pair % p.seg_max;
     if (t >= p.T) return;
     if (dg_failed(p) || dg_tskip(p, t)) return;
+    // a row holds 8 + 8 list entries: a target far deeper than that is swept by k_merge (a wave per segment), launched
+    // beside this kernel when the batch has such targets (DgParams::q_kmax; 0: every target is taken here)
+    if (p.q_kmax && (uint32_t)(p.aln_begin[t + 1] - p.aln_begin[t]) > p.q_kmax) return;
     const uint32_t *crow = p.cuts + (uint64_t)t * (p.seg_max + 2u);
     const uint32_t nseg = crow[0];
     if (seg >= nseg) return;

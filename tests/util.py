@@ -87,3 +87,20 @@ def batch_from_targets(targets, with_backbone=False):
                      b"".join(qs) or b"", b"".join(ts) or b"",
                      (b"".join(bbs) or b"N") if with_backbone else None,
                      np.array(bb_off, np.uint64) if with_backbone else None)
+
+
+def concat_batches(batches):
+    """Several HostBatches (no backbone) as one: targets in order, blobs concatenated."""
+    from pbdagcon_amd.capi import HostBatch
+    tlen = np.concatenate([b.tlen for b in batches])
+    starts = np.concatenate([b.aln_start for b in batches])
+    lens = np.concatenate([b.aln_len for b in batches])
+    offs, begins, ids = [], [np.zeros(1, np.uint64)], []
+    pos = na = 0
+    for b in batches:
+        offs.append(b.aln_off + np.uint64(pos))
+        begins.append(b.aln_begin[1:] + np.uint64(na))
+        pos += int(b.qstr.size); na += b.n_alns
+        ids.extend(b.ids or ["x%d" % i for i in range(b.n_targets)])
+    return HostBatch(tlen, np.concatenate(begins), starts, np.concatenate(offs), lens,
+                     np.concatenate([b.qstr for b in batches]), np.concatenate([b.tstr for b in batches]), None, None, ids)

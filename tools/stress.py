@@ -1,18 +1,21 @@
 """Randomised parity campaign against the oracle (checker), larger than the test suite: mixed
-lengths, coverages, alphabets, spans, trims, segment / stretch settings."""
+lengths, coverages, alphabets, spans, trims, segment / stretch settings.
+
+    python tools/stress.py [seed0 [rounds]]
+
+make_round(seed0, rnd) is the generator of one round; tests/test_gpu_parity.py replays the rounds that
+caught the exit-tree bug of round 2 (seed 17, rounds 0, 7, 8, 23) through it."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
-from pbdagcon_amd import capi, synth
-from util import batch_from_targets, oracle_batch, random_target
 
-seed0 = int(sys.argv[1]) if len(sys.argv) > 1 else 1
-rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 6
-bad = 0
-for rnd in range(rounds):
+
+def make_round(seed0, rnd):
+    """-> (batch, description, min_cov, min_len, trim, [context keyword sets])"""
+    from pbdagcon_amd import synth
+    from util import batch_from_targets, random_target
     rng = np.random.default_rng(seed0 * 1000 + rnd)
-    t0 = time.time()
     if rnd % 2 == 0:
         # generator-made pileups: mixed lengths, partial spans
         n = int(rng.integers(8, 40))
@@ -37,21 +40,38 @@ for rnd in range(rounds):
     min_cov = int(rng.choice([0, 2, 6]))
     min_len = int(rng.choice([0, 50, 500]))
     trim = int(rng.choice([0, 1, 10, 50, 300]))
-    exp = oracle_batch(b, min_cov, min_len, trim)
-    for kw in (dict(), dict(max_segments=1), dict(max_segments=64, min_segment_len=int(rng.choice([4, 64, 300])))):
-        for shift in (None, "4", "6"):
-            if shift is None: os.environ.pop("DAGCON_EMIT_SHIFT", None)
-            else: os.environ["DAGCON_EMIT_SHIFT"] = shift
-            ctx = capi.Context(min_cov=min_cov, min_len=min_len, trim=trim, **kw)
-            try:
-                got = ctx.consensus(b)
-            except capi.DagconError as e:
-                got = str(e)
-            ctx.close()
-            if got != exp:
-                bad += 1
-                what = got if isinstance(got, str) else [t for t in range(len(exp)) if got[t] != exp[t]][:8]
-                print("MISMATCH", desc, kw, shift, min_cov, min_len, trim, "->", what, flush=True)
-    print(f"round {rnd}: {desc} -c {min_cov} -m {min_len} -t {trim}: ok ({time.time() - t0:.1f} s)", flush=True)
-print("mismatches:", bad)
-sys.exit(1 if bad else 0)
+    kws = (dict(), dict(max_segments=1), dict(max_segments=64, min_segment_len=int(rng.choice([4, 64, 300]))))
+    return b, desc, min_cov, min_len, trim, kws
+
+
+def main():
+    from pbdagcon_amd import capi
+    from util import oracle_batch
+    seed0 = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+    rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+    bad = 0
+    for rnd in range(rounds):
+        t0 = time.time()
+        b, desc, min_cov, min_len, trim, kws = make_round(seed0, rnd)
+        exp = oracle_batch(b, min_cov, min_len, trim)
+        for kw in kws:
+            for shift in (None, "4", "6"):
+                if shift is None: os.environ.pop("DAGCON_EMIT_SHIFT", None)
+                else: os.environ["DAGCON_EMIT_SHIFT"] = shift
+                ctx = capi.Context(min_cov=min_cov, min_len=min_len, trim=trim, **kw)
+                try:
+                    got = ctx.consensus(b)
+                except capi.DagconError as e:
+                    got = str(e)
+                ctx.close()
+                if got != exp:
+                    bad += 1
+                    what = got if isinstance(got, str) else [t for t in range(len(exp)) if got[t] != exp[t]][:8]
+                    print("MISMATCH", desc, kw, shift, min_cov, min_len, trim, "->", what, flush=True)
+        print(f"round {rnd}: {desc} -c {min_cov} -m {min_len} -t {trim}: ok ({time.time() - t0:.1f} s)", flush=True)
+    print("mismatches:", bad)
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
