@@ -55,7 +55,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
-PROFILE_DIR = os.path.join(ROOT, "profiles", "r02")
+PROFILE_DIR = os.path.join(ROOT, "profiles", "r03")
 
 
 def fasta_bytes(batch, results):
@@ -562,13 +562,45 @@ def e2e_pre_leg(n_targets, tlen, coverage, opts):
             pass
 
 
+def config5_leg(local_rank):
+    """The dazcon path's shape from the decoded strings inward (BASELINE configs[4]; its .las/.db surface is not built):
+    400 targets of 2-40 kb, 30 reads each spanning >= 60 % of their target, real backbone, -t 10.  Device time of the
+    second run on a warm context; all 400 targets against the digest the CPU oracle produced (tests/golden/large_hashes.json)."""
+    import importlib.util
+    import numpy as np
+    from pbdagcon_amd import capi, synth
+    spec = importlib.util.spec_from_file_location("make_large_hashes", os.path.join(ROOT, "tests", "golden", "make_large_hashes.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    golden = json.load(open(os.path.join(ROOT, "tests", "golden", "large_hashes.json")))["config5_400xmixedx30_partial"]["sha256"]
+    tl = np.random.default_rng(5).integers(2000, 40000, 400)
+    b5 = synth.make_batch(400, 0, 30, seed=8000, min_span=0.6, tlens=tl, with_backbone=True, threads=min(16, len(os.sched_getaffinity(0))))
+    ctx = capi.Context(device=local_rank, min_cov=6, min_len=500, trim=10)
+    try:
+        ctx.upload(b5); ctx.run(); ctx.fetch()
+        best = None
+        for _ in range(3):
+            ctx.run(); res = ctx.fetch(); tm = ctx.timings()
+            if best is None or tm["ms_total"] < best["ms_total"]:
+                best = tm
+    finally:
+        ctx.close()
+    bases = sum(len(sq) for segs in res for _, _, sq in segs)
+    return {"value": bases / (best["ms_total"] * 1e-3), "unit": "bases/s", "targets": 400, "consensus_bases": bases,
+            "ms": best["ms_total"], "stage_ms": {k: best[k] for k in ("ms_normalize", "ms_build", "ms_merge", "ms_bestpath")},
+            "pieces": best["merge_segments"], "roofline_frac": best["algorithmic_bytes"] / (best["ms_total"] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+            "digest_matches_oracle": m.digest(res) == golden,
+            "what": "config-5 shape (400 targets x 2-40 kb x 30x, spans >= 60 %, real backbone, -c 6 -m 500 -t 10), inputs "
+                    "resident, device pipeline of one batch (best of 3), all 400 targets against the committed oracle digest"}
+
+
 def load_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed PMC summary of this round (collected in
     separate --pmc passes, tools/pmc_summary.py); None when there is none for this workload."""
     try:
         pmc = json.load(open(os.path.join(PROFILE_DIR, "pmc_hbm_traffic.json")))
         key = [k for k in pmc["kernels"] if k.startswith(kernel)][0]
-        return pmc["kernels"][key]["hbm_bytes_per_launch_raw"], pmc.get("source", "profiles/r02/pmc_hbm_traffic.json")
+        return pmc["kernels"][key]["hbm_bytes_per_launch_raw"], pmc.get("source", "profiles/r03/pmc_hbm_traffic.json")
     except Exception:
         return None, None
 
@@ -811,6 +843,8 @@ def worker(args, rank, world, local_rank):
                                                                       res[:args.e2e_targets]))
             if n_gpus == 1 and config1:
                 line["e2e_pre"] = e2e_pre_leg(64, 50000, 60, dict(min_cov=8, min_len=500, trim=50))
+            if n_gpus == 1 and config1:
+                line["config5_shape"] = config5_leg(local_rank)
             if n_gpus == 1:
                 # the N = 1 point of configs[3]: 12 batches of this workload's size streamed through two contexts,
                 # uploads inside the clock; batch 0 is the batch `value` was measured on

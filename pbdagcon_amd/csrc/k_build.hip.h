@@ -805,37 +805,37 @@ __global__ __launch_bounds__(1024) void k_gscan(DgParams p) {
 // first (id of the chain's first vertex), nins.  Returns true for a lane whose chain is folded into an earlier lane's
 // (its arrival cell then becomes DG_CELL_DUP: the column counts as a match, the read brings no in-edge).
 #define DG_CELL_DUP 0x1FFFFFEu
-__device__ __forceinline__ bool dg_emit_fold(unsigned long long em, const bool elig, const uint32_t key, const uint32_t anc,
-                                          const uint32_t first, const uint32_t nins, const uint32_t pos, DgNode *ndt,
-                                          uint32_t *pool, uint32_t *dcell, const int lane) {
+// key of a chain that closed at position pos: its (at most three) inserted bases, and in the top byte how far back the
+// backbone vertex in front of it lies (1: the usual insertion, 2: the insertion half of a substitution, ...); 0 = no
+// chain to compare.  Chains at one position with equal keys are duplicates.
+__device__ __forceinline__ bool dg_emit_fold(unsigned long long em, const uint32_t key, const uint32_t first, const uint32_t pos,
+                                             DgNode *ndt, uint32_t *pool, uint32_t *n_out, const int lane) {
     bool victim = false;
-    while (em) {
+    *n_out = 0;
+    while (em & (em - 1ull)) {                            // two or more chains left to compare
         const int f = __ffsll((long long)em) - 1;
-        const uint32_t kf = (uint32_t)__builtin_amdgcn_readlane((int)key, f), af = (uint32_t)__builtin_amdgcn_readlane((int)anc, f);
-        const unsigned long long same = __ballot(elig && key == kf && anc == af);
+        const uint32_t kf = (uint32_t)__builtin_amdgcn_readlane((int)key, f);
+        const unsigned long long same = __ballot(key == kf);
         em &= ~same;
         const uint32_t n = (uint32_t)__popcll(same);
-        if (n < 2) {
-            if (!(em & (em - 1ull))) break;               // one chain left: nothing to pair it with
-            continue;
-        }
-        if (!((same >> lane) & 1ull)) continue;
+        if (n < 2 || !((same >> lane) & 1ull)) continue;
+        const uint32_t nins = (key & 0xFF0000u) ? 3u : (key & 0xFF00u) ? 2u : 1u;
         if (lane == f) {
             // the survivor: every vertex of the chain weighs n, every edge along it counts n (u's out-entry for its
             // first vertex gets its count from the departure cell: k_lists)
+            *n_out = n;
             for (uint32_t k = 0; k < nins; k++) {
                 const uint32_t id = first + k, rk = id - pos;
                 reinterpret_cast<DgNode *>(reinterpret_cast<char *>(ndt) + (id << 5))->weight = (int32_t)n;
                 pool[3u * rk + 1u] = n;
             }
-            *dcell = (first + 1u) | ((n - 1u) << 25);
         } else {
             victim = true;
             for (uint32_t k = 0; k < nins; k++) {
-                DgNode *nd = reinterpret_cast<DgNode *>(reinterpret_cast<char *>(ndt) + ((first + k) << 5));
-                nd->out_len = 0; nd->in_len = 0; nd->flags = DG_NF_DELETED;      // AlnGraphBoost.cpp:269-273
+                // out_len = in_len = 0, flags = deleted (AlnGraphBoost.cpp:269-273); the base stays
+                const uint32_t base = (key >> (8u * (nins - 1u - k))) & 0xFFu;
+                *reinterpret_cast<uint2 *>(reinterpret_cast<char *>(ndt) + ((first + k) << 5)) = make_uint2(0u, base | (DG_NF_DELETED << 8));
             }
-            *dcell = 0u;
         }
     }
     return victim;
@@ -991,23 +991,23 @@ __global__ __launch_bounds__(64) void k_emit(DgParams p) {
 #pragma unroll
         for (int j = 0; j < DG_EB; j++) {
             const uint32_t pos = pos0 + j;
-            bool f_elig = false;
-            uint32_t f_anc = 0, f_apos = 0, f_key = 0, f_n = 0, f_first = 0;
+            bool f_closed = false;
+            uint32_t f_apos = 0, f_key = 0, f_first = 0;
             if (!done && bbpos == pos && pos < P1) {
                 // columns in front of this position that do not advance the backbone cursor:
                 // insertions (AlnGraphBoost.cpp:95-104); raw columns that match no branch are skipped
                 uint32_t ins_id = 0;
                 bool ins_open = false, have = false;
                 uint16_t c = 0;
-                f_anc = prev; f_apos = prev_pos; f_key = 0; f_n = 0;
-                const bool f_anc_ok = prev_bb && own;
+                f_apos = prev_pos;
+                const bool f_anc_ok = prev_bb && own && pos - prev_pos < 16u;
                 while (i < hi) {
                     DG_COLUMN(i, c);
                     const uint8_t qb = DG_Q(c), tb = DG_T(c);
                     if (qb == tb || qb == DG_GAP) { have = true; break; }
                     if (tb == DG_GAP) {
                         if (!ins_open) { ins_open = true; ins_id = gbv[j] + cmv[j]; f_first = ins_id; }
-                        f_key = (f_key << 8) | qb; f_n++;
+                        f_key = (f_key << 8) | qb;
                         const uint32_t id = ins_id++;
                         const uint32_t rk = id - bbpos;   // bbpos backbone vertices precede group bbpos
                         DgNode nd;
@@ -1034,7 +1034,9 @@ __global__ __launch_bounds__(64) void k_emit(DgParams p) {
                     if (qb == tb) {                       // match (:75-85)
                         const uint32_t cur = bidv[j];
                         acell[j] = ((uint32_t)tb << 25) | (prev + 1u);
-                        f_elig = f_anc_ok && f_n >= 1u && f_n <= 4u;
+                        // (a chain of one to three vertices between a backbone vertex and this match: dg_emit_fold)
+                        if (f_anc_ok && f_key != 0u && f_key < (1u << 24)) f_key |= (pos - f_apos) << 24; else f_key = 0;
+                        f_closed = true;
                         DG_DEPART(cur);
                         prev = cur; prev_pos = bbpos; prev_bb = true; own = true;
                     } else {                              // deletion (:87-93)
@@ -1046,11 +1048,19 @@ __global__ __launch_bounds__(64) void k_emit(DgParams p) {
             }
             if (p.fold) {
                 // chains that closed at this position, two or more of them: fold the duplicates (dg_emit_fold)
-                const unsigned long long em = __ballot(f_elig);
-                if (__popcll(em) >= 2) {
-                    uint32_t *dcell = f_apos >= pos0 ? &s_D[(f_apos - pos0) * 64 + lane] : &DG_ECELL(Dm, f_apos);
-                    if (dg_emit_fold(em, f_elig, f_key, f_anc, f_first, f_n, pos, ndt, pool, dcell, lane))
-                        acell[j] = (acell[j] & 0xFE000000u) | DG_CELL_DUP;
+                if (!f_closed) f_key = 0;
+                const unsigned long long em = __ballot(f_key != 0u);
+                if (em & (em - 1ull)) {
+                    uint32_t fn;
+                    const bool vic = dg_emit_fold(em, f_key, f_first, pos, ndt, pool, &fn, lane);
+                    if (vic || fn) {
+                        // the departure cell of the vertex in front: the survivor's carries the reads folded into its
+                        // chain (k_lists counts the out-edge with them), a victim's is empty
+                        const uint32_t dv = vic ? 0u : (f_first + 1u) | ((fn - 1u) << 25);
+                        if (f_apos >= pos0) s_D[(f_apos - pos0) * 64 + lane] = dv;
+                        else DG_ECELL(Dm, f_apos) = dv;
+                        if (vic) acell[j] = (acell[j] & 0xFE000000u) | DG_CELL_DUP;
+                    }
                 }
             }
         }
