@@ -94,6 +94,7 @@ struct Ctx {
 
     // host copy of the filtered batch
     uint32_t T = 0, A = 0;
+    int bp_fused = 1;                              // partial-span bestPath: one (A, B) sweep + vertex-parallel kernels (DAGCON_BP_FUSED=0: three sweeps)
     int fold = 1;                                  // duplicate insertion chains folded by k_emit (DAGCON_FOLD=0: never)
     int merge_q = 1, use_q = 0;                    // k_merge_q: four segments per wave (DAGCON_MERGE_Q=0: never); this batch
     uint32_t max_k = 0, max_tlen = 0;
@@ -120,7 +121,7 @@ struct Ctx {
         d_n_lb, d_norm_tmp, d_ckpt, d_ck_base;
     DevBuf d_node_base, d_n_nodes, d_pool_base, d_pool_size, d_pool_top, d_t_nins;
     DevBuf d_matA, d_matD, d_matC, d_cov, d_gcount, d_gbase, d_bid;
-    DevBuf d_nodes, d_best, d_queue, d_score, d_cns_tmp, d_bp_tt;
+    DevBuf d_nodes, d_best, d_queue, d_score, d_cns_tmp, d_bp_tt, d_score_b;
     DevBuf d_pool, d_stk, d_cuts, d_cuts_bp, d_bp_stat, d_bp_len, d_nextcut, d_tile_list, d_rd, d_pro_state, d_sh_cnt, d_seg_done, d_wl_first, d_queue0, d_bp_end, d_bp_ab, d_defer, d_cns_tmp0;
     DevBuf d_al[14];                                // dagcon_align: blobs, offsets, outputs, directions, launch order, widths
     DevBuf d_cns, d_cns_off, d_cns_len, d_seg_first, d_n_seg, d_seg_r0, d_seg_r1, d_st;
@@ -214,6 +215,7 @@ int ensure_arenas(Ctx *c) {
     ENSURE(c, c->d_queue, c->node_cap * 4);
     ENSURE(c, c->d_score, c->node_cap * 8);
     ENSURE(c, c->d_bp_tt, c->node_cap * 4);
+    if (c->gcuts && c->bp_fused) ENSURE(c, c->d_score_b, c->node_cap * 4);
     ENSURE(c, c->d_cns_tmp, c->node_cap);
     ENSURE(c, c->d_pool, c->pool_cap * 4);
     ENSURE(c, c->d_stk, std::max<uint64_t>((uint64_t)c->T * std::max(c->bp_max, c->seg_max), (c->tile_pos || c->gcuts) ? c->list_grid : 0) * c->stk_words * 4);
@@ -293,6 +295,7 @@ void fill_params(Ctx *c, DgParams &p) {
 #else
     p.pf_ahead = 0;
 #endif
+    p.bp_fused = c->bp_fused ? 1u : 0u; p.score_b = (float *)c->d_score_b.p;
     p.fold = (c->fold && !(c->opts.flags & DAGCON_FLAG_STOP_AFTER_BUILD)) ? 1u : 0u;
     p.q_kmax = c->use_q && !c->opts.max_segments && !c->seg_env && c->max_k > DQ_KMAX ? DQ_KMAX : 0u;
     p.seg_max = c->seg_max; p.seg_min = c->seg_min; p.cuts = (uint32_t *)c->d_cuts.p; p.bp_max = c->bp_max; p.cuts_bp = (uint32_t *)c->d_cuts_bp.p; p.bp_stat = (float *)c->d_bp_stat.p; p.bp_len = (uint32_t *)c->d_bp_len.p;
@@ -387,11 +390,19 @@ int launch_all(Ctx *c) {
         if (c->gcuts && !c->tile_pos) {
             // partial-span pileups: the pieces of k_cuts2, three sweeps (A, B, absolute), see dg_bp_sweep
             hipLaunchKernelGGL(k_bp_xtree, dim3(c->T), dim3(64), 0, s, p);
-            hipLaunchKernelGGL(k_bp_sweep_g<0>, dim3(c->T * c->bp_max), dim3(64), 0, s, p);
-            hipLaunchKernelGGL(k_bp_reset_def, dim3(c->T), dim3(64), 0, s, p);
-            hipLaunchKernelGGL(k_bp_sweep_g<1>, dim3(c->T * c->bp_max), dim3(64), 0, s, p);
-            hipLaunchKernelGGL(k_bp_comb, dim3(c->T), dim3(64), 0, s, p);
-            hipLaunchKernelGGL(k_bp_sweep_g<2>, dim3(c->T * c->bp_max), dim3(64), 0, s, p);
+            if (p.bp_fused) {
+                // one sweep for (A, B), then vertex-parallel kernels for the absolute scores and the choices
+                hipLaunchKernelGGL(k_bp_sweep_ab, dim3(c->T * c->bp_max), dim3(64), 0, s, p);
+                hipLaunchKernelGGL(k_bp_comb, dim3(c->T), dim3(64), 0, s, p);
+                hipLaunchKernelGGL(k_bp_abs, dim3(c->T * c->bp_max), dim3(256), 0, s, p);
+                hipLaunchKernelGGL(k_bp_choose, dim3(c->T * c->bp_max), dim3(256), 0, s, p);
+            } else {
+                hipLaunchKernelGGL(k_bp_sweep_g<0>, dim3(c->T * c->bp_max), dim3(64), 0, s, p);
+                hipLaunchKernelGGL(k_bp_reset_def, dim3(c->T), dim3(64), 0, s, p);
+                hipLaunchKernelGGL(k_bp_sweep_g<1>, dim3(c->T * c->bp_max), dim3(64), 0, s, p);
+                hipLaunchKernelGGL(k_bp_comb, dim3(c->T), dim3(64), 0, s, p);
+            }
+            hipLaunchKernelGGL(k_bp_sweep_g<2>, dim3(c->T * c->bp_max), dim3(64), 0, s, p);     // (fused: whole-target sweeps only)
             hipLaunchKernelGGL(k_bp_defer, dim3(c->T), dim3(64), 0, s, p);
             hipLaunchKernelGGL(k_bp_walk_g, dim3(c->T * c->bp_max), dim3(64), 0, s, p);
         } else {
@@ -446,6 +457,7 @@ int dagcon_create(const dagcon_opts *opts, dagcon_ctx **out) {
         if (v >= 1 && v <= 64) c->seg_env = (uint32_t)v;
     }
     if (const char *e = getenv("DAGCON_FOLD")) c->fold = atoi(e) != 0;
+    if (const char *e = getenv("DAGCON_BP_FUSED")) c->bp_fused = atoi(e) != 0;
     if (const char *e = getenv("DAGCON_MERGE_Q")) c->merge_q = atoi(e) != 0;     // four segments per wave (k_merge_q.hip.h)
     memset(&c->tm, 0, sizeof c->tm);
     memset(&c->h_st, 0, sizeof c->h_st);
@@ -472,7 +484,7 @@ void dagcon_destroy(dagcon_ctx *ctx) {
                      &c->d_n_ins, &c->d_n_del, &c->d_norm, &c->d_node_base, &c->d_n_nodes,
                      &c->d_pool_base, &c->d_pool_size, &c->d_pool_top, &c->d_t_nins, &c->d_matA, &c->d_matD,
                      &c->d_matC, &c->d_cov, &c->d_gcount, &c->d_gbase, &c->d_bid, &c->d_nodes,
-                     &c->d_best, &c->d_queue, &c->d_score, &c->d_cns_tmp, &c->d_bp_tt, &c->d_pool, &c->d_stk, &c->d_cuts, &c->d_cuts_bp, &c->d_bp_stat, &c->d_bp_len, &c->d_nextcut, &c->d_tile_list, &c->d_rd, &c->d_pro_state, &c->d_sh_cnt, &c->d_seg_done, &c->d_wl_first, &c->d_queue0, &c->d_bp_end, &c->d_bp_ab, &c->d_defer, &c->d_cns_tmp0, &c->d_cns,
+                     &c->d_best, &c->d_queue, &c->d_score, &c->d_cns_tmp, &c->d_bp_tt, &c->d_score_b, &c->d_pool, &c->d_stk, &c->d_cuts, &c->d_cuts_bp, &c->d_bp_stat, &c->d_bp_len, &c->d_nextcut, &c->d_tile_list, &c->d_rd, &c->d_pro_state, &c->d_sh_cnt, &c->d_seg_done, &c->d_wl_first, &c->d_queue0, &c->d_bp_end, &c->d_bp_ab, &c->d_defer, &c->d_cns_tmp0, &c->d_cns,
                      &c->d_cns_off, &c->d_cns_len, &c->d_seg_first, &c->d_n_seg, &c->d_seg_r0, &c->d_seg_r1,
                      &c->d_st};
     for (DevBuf *b : all) free_buf(*b);

@@ -155,6 +155,8 @@ struct DgParams {
     int32_t *best, *queue;
     float2 *score;                 // (best-path score, 1 = final)
     float *bp_tt;                  // per vertex: what an edge into it subtracts (k_bp_terms)
+    float *score_b;                // per vertex (p.gcuts, p.bp_fused): B, best path to exit that does not pass the piece's upper cut
+    uint32_t bp_fused;             // 1: partial-span bestPath as one (A, B) sweep + vertex-parallel kernels (k_bp_sweep_ab)
     uint8_t *cns_tmp;
     uint64_t node_cap;
     uint32_t *pool;

@@ -774,6 +774,20 @@ int main(int argc, char **argv) {
             stop = true;
             if (worker_status && !status) status = worker_status;
         }
+        // Every record is printed: nothing of the run is left but giving memory back -- the contexts' arenas (tens of GB
+        // of hipFree), page-locked blobs, the mapping of the input (0.09 s at 1,000 targets, 0.3 - 0.9 s at 20,000) --
+        // which the kernel does for a process that ends, at once.  PBDAGCON_TEARDOWN=1 keeps the orderly way
+        // (the tests' leak checks, tools that time it).
+        if (!getenv("PBDAGCON_TEARDOWN") && !status) {
+            fflush(stdout);
+            if (timing)
+                fprintf(stderr, "pbdagcon timing: total %.3f = parse loop %.3f (index %.3f  fill %.3f  wait-for-buffer %.3f) + drain %.3f, no teardown | "
+                        "worker 0: create %.3f; all workers: flush %.3f (upload %.3f  run %.3f  fetch %.3f)  print %.3f\n",
+                        now() - t_main, t_parse_end - t_main, t_index, t_fill, t_wait, now() - t_parse_end, t_create, t_flush,
+                        g_t_upload, g_t_run, g_t_fetch, t_print);
+            fflush(stderr);
+            _exit(0);
+        }
         cv.notify_all();
         for (auto &w : workers) w.join();
     }

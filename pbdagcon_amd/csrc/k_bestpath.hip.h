@@ -90,6 +90,9 @@ struct DgBpShared {
     int rbest[DG_BR];
     float rscore[DG_BR];                 // results of the chunk being swept, flushed at its end
 };
+struct DgBpSharedB {                     // the AB sweep's second value of a vertex (B next to A): k_bp_sweep_ab only, so that the
+    float svalb[DG_SR], rscoreb[DG_BR];  // other sweeps keep their LDS footprint (it bounds their waves in flight)
+};
 struct DgWalkShared {
     unsigned char wbuf[64];              // consensus bases of the walk, flushed 64 at a time
     int wtag[DG_WR], wbest[DG_WR], wbase[DG_WR], wweight[DG_WR];   // the walk's staging ring
@@ -116,16 +119,23 @@ struct DgWalkShared {
 #define DG_BP_PIECES 256          // most pieces of a target's bestPath sweep (full-span path; 64 with p.gcuts)
 #define DG_BP_NINF (-1.0e9f)
 #define DG_BP_ONE 0xFFFFFFFFu      // DgParams::defer[0]: the target is swept in one piece; bp_end of the first piece: it ended at exit
+// AB: one sweep carries both values of the (max, +) decomposition, A[x] = best x -> upper cut (cut worth 0, exit
+// -inf) in score[].x and B[x] = best x -> exit past it (cut -inf, exit and the exit tree worth their absolute scores)
+// in score_b[]; no choices are recorded (best[] is k_bp_choose's, from the absolute scores k_bp_abs makes of them).
+template <bool AB = false>
 __device__ __forceinline__ void dg_bp_sweep(DgBpShared &S, const DgNode *nd, int32_t *best, float2 *score,
                                             const uint32_t *pool, const float *tt, const int v_top, const int v_bot,
                                             const int c_top, int32_t *gstk, const int gstk_cap,
                                             const int lane, float &amax, bool &bad, bool &stuck,
                                             const float ctv = 0.0f, const int xid = -1, const float xv = 0.0f,
-                                            const bool skip_def = false) {
+                                            const bool skip_def = false, float *score_b = nullptr, DgBpSharedB *SB = nullptr) {
     const int dead_mask = (int)DG_NF_DELETED | (skip_def ? (int)DG_NF_DEFER : 0);
     for (int i = lane; i < DG_SR; i += 64) S.stag[i] = -1;
     for (int i = lane; i < DG_BR; i += 64) S.tag[i] = -1;
-    if (c_top >= 0 && lane == 0) { S.stag[c_top & (DG_SR - 1)] = c_top; S.sval[c_top & (DG_SR - 1)] = ctv; }
+    if (c_top >= 0 && lane == 0) {
+        S.stag[c_top & (DG_SR - 1)] = c_top; S.sval[c_top & (DG_SR - 1)] = ctv;
+        if constexpr (AB) SB->svalb[c_top & (DG_SR - 1)] = DG_BP_NINF;
+    }
 
     // ---- staging registers: r_* = records of a chunk, e_* = its edges ----
     uint4 r_lo, r_hi, n_lo, n_hi;
@@ -264,17 +274,21 @@ __device__ __forceinline__ void dg_bp_sweep(DgBpShared &S, const DgNode *nd, int
                     const int y = d & (DG_SR - 1);
                     const int stg = S.stag[y];
                     const float ns = w + S.sval[y];
+                    float nsb = 0.0f;
+                    if constexpr (AB) nsb = w + SB->svalb[y];
                     const bool ok = lane >= ol || stg == d;
                     if (__all(ok)) {
                         // :399-416 first maximum in list order, strict '>'
-                        float mx = 0.0f;
+                        float mx = 0.0f, mxb = 0.0f;
                         int bd = -1;
                         if (ol > 0) {
                             mx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ns), 0));
                             bd = __builtin_amdgcn_readlane(d, 0);
+                            if constexpr (AB) mxb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(nsb), 0));
                             for (int i = 1; i < ol; i++) {
                                 const float xsx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ns), i));
                                 if (xsx > mx) { mx = xsx; bd = __builtin_amdgcn_readlane(d, i); }
+                                if constexpr (AB) mxb = fmaxf(mxb, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(nsb), i)));
                             }
                         }
                         if (lane == 0) {
@@ -282,8 +296,10 @@ __device__ __forceinline__ void dg_bp_sweep(DgBpShared &S, const DgNode *nd, int
                             S.sval[v & (DG_SR - 1)] = mx;
                             S.rscore[xs] = mx; S.rbest[xs] = bd;
                             S.lens[xs] = ln | DG_BL_DONE;
+                            if constexpr (AB) { SB->svalb[v & (DG_SR - 1)] = mxb; SB->rscoreb[xs] = mxb; }
                         }
                         if (mx > 0.5f * DG_BP_NINF) amax = fmaxf(amax, fabsf(mx));
+                        if constexpr (AB) if (mxb > 0.5f * DG_BP_NINF) amax = fmaxf(amax, fabsf(mxb));
                         if (ndef) woken = collect(v, 0);          // (rare: somebody far above waits for v)
                         if (!woken) continue;
                     }
@@ -322,7 +338,7 @@ __device__ __forceinline__ void dg_bp_sweep(DgBpShared &S, const DgNode *nd, int
                     out_off = __builtin_amdgcn_readfirstlane(nn.out_off);
                     out_len = __builtin_amdgcn_readfirstlane((int)nn.out_len);
                 }
-                float mx = 0.0f;          // no out edge (the exit vertex): score 0, the map default
+                float mx = 0.0f, mxb = 0.0f;   // no out edge (the exit vertex): score 0, the map default
                 int bd = -1;
                 bool again = false;
                 for (int e0 = 0; e0 < out_len; e0 += 64) {
@@ -340,19 +356,25 @@ __device__ __forceinline__ void dg_bp_sweep(DgBpShared &S, const DgNode *nd, int
                     }
                     const int y = d & (DG_SR - 1);
                     const int stg = S.stag[y];
-                    float sc = S.sval[y];
+                    float sc = S.sval[y], scb = 0.0f;
+                    if constexpr (AB) scb = SB->svalb[y];
                     bool have = valid && stg == d;
                     if (valid && !have) {
                         // the score ring holds the last 1024 finished ids only (a long turned-around
                         // edge makes thousands finish early): a vertex of a resident chunk keeps its
                         // result in its slot until the chunk's row store, everything else is in HBM
                         const int yd = d & (DG_BR - 1);
-                        if (d == c_top) { have = true; sc = ctv; }        // the segment's reference point
-                        else if (d == xid) { have = true; sc = xv; }      // an edge to the exit vertex, which lies beyond the stretch
-                        else if (S.tag[yd] == d && (S.lens[yd] & DG_BL_DONE) && d >= v_lo) { have = true; sc = S.rscore[yd]; }
-                        else {
+                        if (d == c_top) { have = true; sc = ctv; if constexpr (AB) scb = DG_BP_NINF; }   // the segment's reference point
+                        else if (d == xid) { have = true; sc = xv; if constexpr (AB) scb = 0.0f; }      // an edge to the exit vertex, which lies beyond the stretch
+                        else if (S.tag[yd] == d && (S.lens[yd] & DG_BL_DONE) && d >= v_lo) {
+                            have = true; sc = S.rscore[yd];
+                            if constexpr (AB) scb = SB->rscoreb[yd];
+                        } else {
                             const float2 sg = score[d];
-                            if (sg.y >= 1.0f) { have = true; sc = (sg.y == 2.0f && xv < 0.5f * DG_BP_NINF) ? xv : sg.x; }   // (2.0: k_bp_xtree)
+                            if (sg.y >= 1.0f) {
+                                have = true; sc = (sg.y == 2.0f && xv < 0.5f * DG_BP_NINF) ? xv : sg.x;    // (2.0: k_bp_xtree)
+                                if constexpr (AB) scb = sg.y == 2.0f ? sg.x : score_b[d];
+                            }
                         }
                     }
                     const unsigned long long miss = __ballot(valid && !have);
@@ -389,10 +411,14 @@ __device__ __forceinline__ void dg_bp_sweep(DgBpShared &S, const DgNode *nd, int
                     // :399-416 first maximum in list order, strict '>'
                     const float ns = w + sc;
                     const int cnt = out_len - e0 < 64 ? out_len - e0 : 64;
-                    if (e0 == 0) mx = -FLT_MAX;
+                    if (e0 == 0) { mx = -FLT_MAX; mxb = -FLT_MAX; }
                     for (int i = 0; i < cnt; i++) {
                         const float xs = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ns), i));
                         if (xs > mx) { mx = xs; bd = __builtin_amdgcn_readlane(d, i); }
+                    }
+                    if constexpr (AB) {
+                        const float nsb = w + scb;
+                        for (int i = 0; i < cnt; i++) mxb = fmaxf(mxb, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(nsb), i)));
                     }
                 }
                 if (bad) break;
@@ -400,18 +426,21 @@ __device__ __forceinline__ void dg_bp_sweep(DgBpShared &S, const DgNode *nd, int
                 if (lane == 0) {
                     S.stag[n & (DG_SR - 1)] = n;
                     S.sval[n & (DG_SR - 1)] = mx;
+                    if constexpr (AB) SB->svalb[n & (DG_SR - 1)] = mxb;
                     if (in_ring && n >= v_lo && n <= v_hi) {   // this chunk: HBM gets it at the end of the chunk
                         S.rscore[x] = mx; S.rbest[x] = bd;
+                        if constexpr (AB) SB->rscoreb[x] = mxb;
                         S.lens[x] = lens | DG_BL_DONE;
                     } else {
                         score[n] = make_float2(mx, 1.0f);
-                        best[n] = bd;
+                        if constexpr (AB) score_b[n] = mxb; else best[n] = bd;
                         if (in_ring) S.lens[x] = lens | DG_BL_DONE;
                     }
                 }
                 // (a vertex scored before its chunk is unpacked is scored again at its turn:
                 // same successors, same result)
                 if (mx > 0.5f * DG_BP_NINF) amax = fmaxf(amax, fabsf(mx));
+                if constexpr (AB) if (mxb > 0.5f * DG_BP_NINF) amax = fmaxf(amax, fabsf(mxb));
                 sp--;
                 if (ndef) {                                // those that waited for n are next
                     if (sp + 1 + ndef > DG_BSTK + gstk_cap) { bad = true; break; }
@@ -426,7 +455,10 @@ __device__ __forceinline__ void dg_bp_sweep(DgBpShared &S, const DgNode *nd, int
             const int id = v_hi - lane;
             if (id >= v_lo) {
                 const int xr = id & (DG_BR - 1);
-                if (S.lens[xr] & DG_BL_DONE) { score[id] = make_float2(S.rscore[xr], 1.0f); best[id] = S.rbest[xr]; }
+                if (S.lens[xr] & DG_BL_DONE) {
+                    score[id] = make_float2(S.rscore[xr], 1.0f);
+                    if constexpr (AB) score_b[id] = SB->rscoreb[xr]; else best[id] = S.rbest[xr];
+                }
             }
         }
         // the target terms of the edges that wait in e_* (requested a chunk ago: they are here)
@@ -759,6 +791,7 @@ __global__ __launch_bounds__(64) void k_bp_sweep_g(DgParams p) {
         dg_bp_sweep(S, p.nodes + nb, p.best + nb, score, p.pool + p.pool_base[t], p.bp_tt + nb, N - 1, 0, -1,
                     p.stk + (uint64_t)blockIdx.x * p.stk_words, (int)p.stk_words, lane, amax, bad, stuck);
     } else {
+        if (p.bp_fused) return;                                // (k_bp_sweep_ab / k_bp_abs / k_bp_choose did the pieces)
         const bool last = seg + 1 == nseg;
         if (last && PASS != 0) return;
         const int c_bot = (int)crow[1 + seg];
@@ -785,6 +818,109 @@ __global__ __launch_bounds__(64) void k_bp_sweep_g(DgParams p) {
         }
     }
     if (bad && lane == 0) { if (stuck) dg_fail_target(p, t, DG_E_INTERNAL); else { dg_fail(p, DG_E_STACK); p.st->bad_target = t; } }
+}
+
+// ---- the pieces in ONE sweep (p.bp_fused) -------------------------------------------------------------------------
+// A and B of every vertex come out of the same pass (dg_bp_sweep<true>): they are the same recurrence on the same edges
+// with different boundary values, and nothing is decided in it.  k_bp_comb turns the pieces' (A, B) into the absolute
+// score of every cut as before; then the absolute score of every vertex is an elementwise max(A + score[cut], B)
+// (k_bp_abs) and its first-maximum choice a loop over its own out-list (k_bp_choose): vertex-parallel kernels instead of
+// a second and a third sequential sweep.  Exact for the reason the three-sweep form is (all values multiples of 0.5
+// below 2^22: k_bp_comb's bound); k_bp_choose checks it on the way -- the maximum it finds must BE the vertex's
+// absolute score, else the target is swept again in one piece.
+__global__ __launch_bounds__(64) void k_bp_sweep_ab(DgParams p) {
+    const uint32_t t = blockIdx.x / p.bp_max, seg = blockIdx.x % p.bp_max;
+    if (dg_failed(p) || dg_tskip(p, t)) return;
+    const uint32_t *crow = p.cuts_bp + (uint64_t)t * (p.bp_max + 2u);
+    const uint32_t nseg = crow[0];
+    if (seg >= nseg) return;
+    if (p.defer[(uint64_t)t * (DG_DEFER_MAX + 1u)] == DG_BP_ONE || nseg <= 1) return;       // k_bp_sweep_g<2> has it, whole
+    const int lane = threadIdx.x;
+    const uint64_t nb = p.node_base[t];
+    __shared__ DgBpShared S;
+    __shared__ DgBpSharedB SB;
+    const int N = (int)p.n_nodes[t];
+    float2 *score = p.score + nb;
+    float amax = 0.0f;
+    bool bad = false, stuck = false;
+    const bool last = seg + 1 == nseg;
+    const int c_bot = (int)crow[1 + seg];
+    const int c_top = last ? -1 : (int)crow[2 + seg];
+    const int v_top = last ? N - 1 : c_top - 1;
+    float *ab = p.bp_ab + 4ull * blockIdx.x;
+    if (last)       // the last piece ends in exit: its scores are absolute at once, its choices final
+        dg_bp_sweep<false>(S, p.nodes + nb, p.best + nb, score, p.pool + p.pool_base[t], p.bp_tt + nb, v_top, c_bot, c_top,
+                           p.stk + (uint64_t)blockIdx.x * p.stk_words, (int)p.stk_words, lane, amax, bad, stuck,
+                           0.0f, -1, 0.0f, true);
+    else
+        dg_bp_sweep<true>(S, p.nodes + nb, p.best + nb, score, p.pool + p.pool_base[t], p.bp_tt + nb, v_top, c_bot, c_top,
+                          p.stk + (uint64_t)blockIdx.x * p.stk_words, (int)p.stk_words, lane, amax, bad, stuck,
+                          0.0f, N - 1, DG_BP_NINF, true, p.score_b + nb, &SB);
+    if (!bad) {
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        const float a = score[c_bot].x;                    // (piece 0 begins with enter, which is deferred: not used)
+        const float b = last ? 0.0f : p.score_b[nb + c_bot];
+        if (lane == 0) { ab[0] = a; ab[1] = b; ab[3] = amax; }
+    }
+    if (bad && lane == 0) { if (stuck) dg_fail_target(p, t, DG_E_INTERNAL); else { dg_fail(p, DG_E_STACK); p.st->bad_target = t; } }
+}
+
+// absolute scores of the pieces' vertices: max(A + score[upper cut], B); one block per (target, piece)
+__global__ __launch_bounds__(256) void k_bp_abs(DgParams p) {
+    const uint32_t t = blockIdx.x / p.bp_max, seg = blockIdx.x % p.bp_max;
+    if (dg_failed(p) || dg_tskip(p, t)) return;
+    const uint32_t *crow = p.cuts_bp + (uint64_t)t * (p.bp_max + 2u);
+    const uint32_t nseg = crow[0];
+    if (seg + 1 >= nseg) return;                                       // (the last piece is absolute already)
+    if (p.defer[(uint64_t)t * (DG_DEFER_MAX + 1u)] == DG_BP_ONE) return;
+    const uint64_t nb = p.node_base[t];
+    const float s = p.bp_ab[4ull * blockIdx.x + 2];
+    const int c_bot = (int)crow[1 + seg], c_top = (int)crow[2 + seg];
+    for (int v = c_bot + (int)threadIdx.x; v < c_top; v += 256) {
+        const float2 sg = p.score[nb + v];
+        if (sg.y != 1.0f) continue;                                    // not scored (deleted, deferred) or the exit tree's (2.0: absolute)
+        const float via_a = sg.x + s, via_b = p.score_b[nb + v];
+        p.score[nb + v] = make_float2(via_a > via_b ? via_a : via_b, 1.0f);
+    }
+}
+
+// the first-maximum choice of every vertex of the pieces (AlnGraphBoost.cpp:399-416), from absolute scores
+__global__ __launch_bounds__(256) void k_bp_choose(DgParams p) {
+    const uint32_t t = blockIdx.x / p.bp_max, seg = blockIdx.x % p.bp_max;
+    if (dg_failed(p) || dg_tskip(p, t)) return;
+    const uint32_t *crow = p.cuts_bp + (uint64_t)t * (p.bp_max + 2u);
+    const uint32_t nseg = crow[0];
+    if (seg + 1 >= nseg) return;
+    uint32_t *dl = p.defer + (uint64_t)t * (DG_DEFER_MAX + 1u);
+    if (dl[0] == DG_BP_ONE) return;
+    const uint64_t nb = p.node_base[t];
+    const DgNode *nd = p.nodes + nb;
+    const uint32_t *pool = p.pool + p.pool_base[t];
+    const float *tt = p.bp_tt + nb;
+    const float2 *score = p.score + nb;
+    const int c_bot = (int)crow[1 + seg], c_top = (int)crow[2 + seg];
+    bool wrong = false;
+    for (int v = c_bot + (int)threadIdx.x; v < c_top; v += 256) {
+        const float2 sv = score[v];
+        if (sv.y != 1.0f) continue;
+        const uint4 h = *reinterpret_cast<const uint4 *>(&nd[v]);
+        const uint32_t out_len = h.x & 0xffffu, out_off = (reinterpret_cast<const uint4 *>(&nd[v]) + 1)->x;
+        float mx = 0.0f;
+        int bd = -1;
+        for (uint32_t e = 0; e < out_len; e++) {
+            const int d = (int)pool[out_off + 2u * e];
+            const float2 sd = score[d];
+            const float td = tt[d];
+            const float w = td == DG_TT_TEN ? -10.0f : (float)(int)pool[out_off + 2u * e + 1u] - td;     // :404-408
+            const float ns = w + sd.x;
+            // (the exit vertex has no score of its own: 0, the map default; every other successor has one by now)
+            if (sd.y < 1.0f && d != (int)p.n_nodes[t] - 1) wrong = true;
+            if (e == 0 || ns > mx) { mx = ns; bd = d; }                 // strict '>': the first maximum wins
+        }
+        if (mx != sv.x) wrong = true;                                   // the recurrence must hold with the absolute scores
+        p.best[nb + v] = bd;
+    }
+    if (wrong) dl[0] = DG_BP_ONE;                                       // (cannot happen below the 2^22 bound: swept again, whole)
 }
 
 __global__ __launch_bounds__(64) void k_bp_comb(DgParams p) {
