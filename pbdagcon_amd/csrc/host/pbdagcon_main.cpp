@@ -774,22 +774,22 @@ int main(int argc, char **argv) {
             stop = true;
             if (worker_status && !status) status = worker_status;
         }
-        // Every record is printed: nothing of the run is left but giving memory back -- the contexts' arenas (tens of GB
-        // of hipFree), page-locked blobs, the mapping of the input (0.09 s at 1,000 targets, 0.3 - 0.9 s at 20,000) --
-        // which the kernel does for a process that ends, at once.  PBDAGCON_TEARDOWN=1 keeps the orderly way
-        // (the tests' leak checks, tools that time it).
+        cv.notify_all();
+        for (auto &w : workers) w.join();          // (every worker destroys its context: the device memory goes back in order,
+                                                   // so that the next process's large hipMalloc does not wait for it)
+        // Every record is printed and the GPU is released: what is left is host-side tidying -- page-locked blobs, the
+        // mapping of the input, the HIP runtime's own exit handlers (0.1 - 0.3 s at 1,000 targets) -- which the kernel
+        // does for a process that ends, at once.  PBDAGCON_TEARDOWN=1 keeps the orderly way.
         if (!getenv("PBDAGCON_TEARDOWN") && !status) {
             fflush(stdout);
             if (timing)
-                fprintf(stderr, "pbdagcon timing: total %.3f = parse loop %.3f (index %.3f  fill %.3f  wait-for-buffer %.3f) + drain %.3f, no teardown | "
+                fprintf(stderr, "pbdagcon timing: total %.3f = parse loop %.3f (index %.3f  fill %.3f  wait-for-buffer %.3f) + drain %.3f, no host teardown | "
                         "worker 0: create %.3f; all workers: flush %.3f (upload %.3f  run %.3f  fetch %.3f)  print %.3f\n",
                         now() - t_main, t_parse_end - t_main, t_index, t_fill, t_wait, now() - t_parse_end, t_create, t_flush,
                         g_t_upload, g_t_run, g_t_fetch, t_print);
             fflush(stderr);
             _exit(0);
         }
-        cv.notify_all();
-        for (auto &w : workers) w.join();
     }
     t_joined = now();
     for (auto &x : bufs) { x.q.release(); x.t.release(); }
