@@ -20,6 +20,7 @@
 #include "k_build.hip.h"
 #include "k_merge.hip.h"
 #ifdef DG_EXPERIMENTS
+#include "experiments/k_emit2.hip.h"         // addAln with a thread per column: exact, and 15.6 ms of build against 12.4
 #include "experiments/k_merge_tile.hip.h"     // dropped experiments: `make experiments` only, never in the shipped library
 #endif
 #include "k_merge_q.hip.h"
@@ -94,6 +95,9 @@ struct Ctx {
 
     // host copy of the filtered batch
     uint32_t T = 0, A = 0;
+    int emit2 = 0;                                 // addAln with a thread per column (k_emit2.hip.h; DAGCON_EMIT2)
+    uint32_t max_len = 0, bs_stride = 0;
+    DevBuf d_matK, d_bbstart;
     int bp_fused = 1;                              // partial-span bestPath: one (A, B) sweep + vertex-parallel kernels (DAGCON_BP_FUSED=0: three sweeps)
     int fold = 1;                                  // duplicate insertion chains folded by k_emit (DAGCON_FOLD=0: never)
     int merge_q = 1, use_q = 0;                    // k_merge_q: four segments per wave (DAGCON_MERGE_Q=0: never); this batch
@@ -295,6 +299,7 @@ void fill_params(Ctx *c, DgParams &p) {
 #else
     p.pf_ahead = 0;
 #endif
+    p.emit2 = c->emit2 ? 1u : 0u; p.matK = (uint8_t *)c->d_matK.p; p.bbstart = (uint32_t *)c->d_bbstart.p; p.bs_stride = c->bs_stride;
     p.bp_fused = c->bp_fused ? 1u : 0u; p.score_b = (float *)c->d_score_b.p;
     p.fold = (c->fold && !(c->opts.flags & DAGCON_FLAG_STOP_AFTER_BUILD)) ? 1u : 0u;
     p.q_kmax = c->use_q && !c->opts.max_segments && !c->seg_env && c->max_k > DQ_KMAX ? DQ_KMAX : 0u;
@@ -348,6 +353,13 @@ int launch_all(Ctx *c) {
         if (c->gcuts && c->A > 0) hipLaunchKernelGGL(k_readspan, dim3((c->A + 63) / 64), dim3(64), 0, s, p);   // (before matC becomes prefix sums)
         hipLaunchKernelGGL(k_groups, dim3(c->T, (c->max_tlen + 2 + 31) / 32), dim3(256), 0, s, p);
         hipLaunchKernelGGL(k_gscan, dim3(c->T), dim3(1024), 0, s, p);
+#ifdef DG_EXPERIMENTS
+        if (c->A > 0 && c->emit2) {
+            hipLaunchKernelGGL(k_blockscan, dim3(c->A), dim3(64), 0, s, p);
+            hipLaunchKernelGGL(k_emit2, dim3((c->bs_stride + 3u) / 4u, c->A), dim3(256), 0, s, p);
+            if (p.fold) hipLaunchKernelGGL(k_dedupe, dim3(c->T, rows4), dim3(256), 0, s, p);
+        } else
+#endif
         if (c->A > 0)
             hipLaunchKernelGGL(k_emit, dim3(c->T, (c->max_k + DG_ERPW - 1) / DG_ERPW, ((c->max_tlen + 2) >> c->emit_shift) + 1),
                                dim3(64), 0, s, p);
@@ -458,6 +470,9 @@ int dagcon_create(const dagcon_opts *opts, dagcon_ctx **out) {
     }
     if (const char *e = getenv("DAGCON_FOLD")) c->fold = atoi(e) != 0;
     if (const char *e = getenv("DAGCON_BP_FUSED")) c->bp_fused = atoi(e) != 0;
+#ifdef DG_EXPERIMENTS
+    if (const char *e = getenv("DAGCON_EMIT2")) c->emit2 = atoi(e) != 0;
+#endif
     if (const char *e = getenv("DAGCON_MERGE_Q")) c->merge_q = atoi(e) != 0;     // four segments per wave (k_merge_q.hip.h)
     memset(&c->tm, 0, sizeof c->tm);
     memset(&c->h_st, 0, sizeof c->h_st);
@@ -484,7 +499,7 @@ void dagcon_destroy(dagcon_ctx *ctx) {
                      &c->d_n_ins, &c->d_n_del, &c->d_norm, &c->d_node_base, &c->d_n_nodes,
                      &c->d_pool_base, &c->d_pool_size, &c->d_pool_top, &c->d_t_nins, &c->d_matA, &c->d_matD,
                      &c->d_matC, &c->d_cov, &c->d_gcount, &c->d_gbase, &c->d_bid, &c->d_nodes,
-                     &c->d_best, &c->d_queue, &c->d_score, &c->d_cns_tmp, &c->d_bp_tt, &c->d_score_b, &c->d_pool, &c->d_stk, &c->d_cuts, &c->d_cuts_bp, &c->d_bp_stat, &c->d_bp_len, &c->d_nextcut, &c->d_tile_list, &c->d_rd, &c->d_pro_state, &c->d_sh_cnt, &c->d_seg_done, &c->d_wl_first, &c->d_queue0, &c->d_bp_end, &c->d_bp_ab, &c->d_defer, &c->d_cns_tmp0, &c->d_cns,
+                     &c->d_best, &c->d_queue, &c->d_score, &c->d_cns_tmp, &c->d_bp_tt, &c->d_score_b, &c->d_matK, &c->d_bbstart, &c->d_pool, &c->d_stk, &c->d_cuts, &c->d_cuts_bp, &c->d_bp_stat, &c->d_bp_len, &c->d_nextcut, &c->d_tile_list, &c->d_rd, &c->d_pro_state, &c->d_sh_cnt, &c->d_seg_done, &c->d_wl_first, &c->d_queue0, &c->d_bp_end, &c->d_bp_ab, &c->d_defer, &c->d_cns_tmp0, &c->d_cns,
                      &c->d_cns_off, &c->d_cns_len, &c->d_seg_first, &c->d_n_seg, &c->d_seg_r0, &c->d_seg_r1,
                      &c->d_st};
     for (DevBuf *b : all) free_buf(*b);
@@ -516,6 +531,7 @@ static int upload_impl(dagcon_ctx *ctx, const dagcon_batch *b, const void *dev_q
     c->h_bbv_base.assign(T, 0);
     c->h_bb_off.assign(T, 0);
     c->h_aln_len.clear(); c->h_aln_start.clear(); c->h_aln_tgt.clear(); c->h_aln_off.clear();
+    c->max_len = 0;
     c->max_k = 0; c->max_tlen = 0; c->sum_len = 0; c->sum_bb = 0; c->mat_cells = 0;
     c->have_bb = b->backbone != nullptr;
     uint64_t bb_bytes = 0, n_whole = 0;
@@ -540,6 +556,7 @@ static int upload_impl(dagcon_ctx *ctx, const dagcon_batch *b, const void *dev_q
             c->h_aln_off.push_back(b->aln_off[a]);
             c->h_aln_tgt.push_back(t);
             c->sum_len += len;
+            c->max_len = std::max(c->max_len, len);
             n_whole += len >= b->tlen[t];                                  // (a read that spans the target has a column per target base)
         }
         const uint64_t k = c->h_aln_len.size() - c->h_aln_begin[t];
@@ -691,7 +708,13 @@ static int upload_impl(dagcon_ctx *ctx, const dagcon_batch *b, const void *dev_q
     ENSURE(c, c->d_node_base, (size_t)T * 8); ENSURE(c, c->d_n_nodes, T4);
     ENSURE(c, c->d_pool_base, (size_t)T * 8); ENSURE(c, c->d_pool_size, T4); ENSURE(c, c->d_pool_top, T4);
     ENSURE(c, c->d_t_nins, T4); ENSURE(c, c->d_tfail, T4 + 4);
-    ENSURE(c, c->d_matA, c->mat_cells * 4); ENSURE(c, c->d_matD, c->mat_cells * 4);
+    if (c->emit2) {
+        // cells as [read][position] rows (k_emit2.hip.h); the chains' keys; backbone position per 64-column block
+        ENSURE(c, c->d_matA, c->matc_cells * 4 + 256); ENSURE(c, c->d_matD, c->matc_cells * 4 + 256);
+        ENSURE(c, c->d_matK, c->matc_cells + 256);
+        c->bs_stride = (uint32_t)((2ull * c->max_len + 63ull) / 64ull + 1ull);
+        ENSURE(c, c->d_bbstart, (uint64_t)std::max<uint32_t>(c->A, 1u) * c->bs_stride * 4);
+    } else { ENSURE(c, c->d_matA, c->mat_cells * 4); ENSURE(c, c->d_matD, c->mat_cells * 4); }
     ENSURE(c, c->d_matC, c->matc_cells * 4 + 256);
     ENSURE(c, c->d_cov, c->sum_bb * 4); ENSURE(c, c->d_gcount, c->sum_bb * 4);
     ENSURE(c, c->d_gbase, c->sum_bb * 4); ENSURE(c, c->d_bid, c->sum_bb * 4);

@@ -146,6 +146,10 @@ struct DgParams {
     int32_t *cov;                  // coverage (AlnGraphBoost.cpp:76,87)
     // ---- matrices [position][read] ----
     uint32_t *matA, *matD;         // arrival / departure
+    uint8_t *matK;                 // (p.emit2) [read][position], a byte: key of the short insertion chain a match column closes (k_dedupe)
+    uint32_t *bbstart;             // (p.emit2) [A][bs_stride]: backbone position at the start of every 64-column block (k_blockscan)
+    uint32_t bs_stride;
+    uint32_t emit2;                // 1: addAln with a thread per column (k_emit2.hip.h): matA / matD are [read][position] like matC
     uint32_t *matC;                // [read][position] (row stride matc_stride): insertion run length in front of
                                    // the position, then its exclusive prefix over reads
     const uint64_t *matc_base;     // [T] offset of the target's K rows

@@ -1143,7 +1143,9 @@ __global__ __launch_bounds__(256) void k_lists(DgParams p) {
     const uint64_t nb = p.node_base[t];
     const uint64_t bv = p.bbv_base[t];
     uint32_t *pool = p.pool + p.pool_base[t];
-    const uint32_t *Am0 = p.matA + p.mat_base[t], *Dm0 = p.matD + p.mat_base[t];
+    // cells of read r at position pos: [position][read] from k_emit, [read][position] (rows as matC's) from k_emit2
+    const uint32_t *Am0 = p.matA + (p.emit2 ? p.matc_base[t] : p.mat_base[t]), *Dm0 = p.matD + (p.emit2 ? p.matc_base[t] : p.mat_base[t]);
+    const uint32_t rstep = p.emit2 ? p.matc_stride[t] : 1u;
     const uint32_t capb = dg_capb(K);
     const uint32_t fixed0 = 3u * p.t_nins[t];
     // a wave takes DG_LPW consecutive positions: the set-up above is paid once for them
@@ -1151,8 +1153,8 @@ __global__ __launch_bounds__(256) void k_lists(DgParams p) {
     const uint32_t pos = (blockIdx.y * 4 + wave) * DG_LPW + pi;
     if (pos >= blen + 2) return;
     const uint32_t v = p.bid[bv + pos];
-    const uint32_t *Am = Am0 + (uint64_t)pos * K;
-    const uint32_t *Dm = Dm0 + (uint64_t)pos * K;
+    const uint32_t *Am = Am0 + (p.emit2 ? (uint64_t)pos : (uint64_t)pos * K);
+    const uint32_t *Dm = Dm0 + (p.emit2 ? (uint64_t)pos : (uint64_t)pos * K);
     const uint32_t fixed = fixed0 + pos * 3u * capb;
     uint32_t out_off = fixed, in_off = fixed + 2u * capb;
     uint32_t out_cap = capb, in_cap = capb;
@@ -1170,7 +1172,7 @@ __global__ __launch_bounds__(256) void k_lists(DgParams p) {
             // its own with no comparing; only the other backbone vertices (deletion jumps, the exit,
             // the enter) are grouped by peeling.  Entries go straight to the pool in the order of
             // their first read. ----
-            const uint32_t cell = (uint32_t)lane < K ? row[lane] : 0u;
+            const uint32_t cell = (uint32_t)lane < K ? row[(uint64_t)lane * rstep] : 0u;
             // departure: neighbour id + 1 (0 = none) and, above bit 25, the reads k_emit folded into this one's chain
             int32_t val = (int32_t)DG_CELL_ID(cell);
             const int32_t extra = (int32_t)(cell >> 25);
@@ -1228,7 +1230,7 @@ __global__ __launch_bounds__(256) void k_lists(DgParams p) {
         bool in_lds = false;
         for (uint32_t r0 = 0; r0 < K; r0 += DG_WAVE) {
             const uint32_t r = r0 + lane;
-            const uint32_t cell = r < K ? row[r] : 0u;
+            const uint32_t cell = r < K ? row[(uint64_t)r * rstep] : 0u;
             int32_t val = (int32_t)DG_CELL_ID(cell);           // neighbour id + 1, 0 = none
             const int32_t extra = dir == 0 ? (int32_t)(cell >> 25) : 0;       // reads folded into this one's chain (k_emit)
             if (dir == 1) {
