@@ -24,7 +24,7 @@
 // k_dedupe 1.6 + k_lists 4.9 (strided cell reads) = build 15.6 ms against 12.4 at configs[1].
 #pragma once
 #include <hip/hip_runtime.h>
-#include "dagcon_dev.h"
+#include "../dagcon_dev.h"
 
 #define E2_N 0   // no vertex, no advance (outside the window; a raw column addAln skips)
 #define E2_M 1

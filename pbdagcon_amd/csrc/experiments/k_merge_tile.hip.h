@@ -24,7 +24,7 @@
 //   [o_grow)   lists that outgrew their slots (bump allocated; flushed to the target's growth region)
 #pragma once
 #include <hip/hip_runtime.h>
-#include "dagcon_dev.h"
+#include "../dagcon_dev.h"
 
 #define DG_T_DEPTH 8            // frames of mergeInNodes' recursion kept per lane (deeper: fallback)
 #define DG_T_NONE 0xFFFFFFFFu
