@@ -259,6 +259,12 @@ int dagcon_debug_graph(dagcon_ctx *ctx, uint32_t target, dagcon_graph_dump *out)
  * run (in-kernel cycle stamps of target 0); all zero in the shipped build. */
 int dagcon_debug_counters(dagcon_ctx *ctx, unsigned long long *out8);
 
+/* Records of the last dagcon_align / dagcon_consensus_pre on this context whose corners the widest band could not
+ * connect (sequences of very different lengths, indels of hundreds of bases): their alignment has length 0 and the
+ * min_len filter then drops them, where the reference's SDPAlign + GuidedAlign (SimpleAligner.cpp:35-48) always
+ * returns something.  The calls succeed; a caller that cares asks here (the pbdagcon host warns on stderr). */
+uint32_t dagcon_align_dropped(dagcon_ctx *ctx);
+
 /* Host arithmetic only (no device, no context): the pieces dagcon_upload would cut the merge and bestPath
  * sweeps of a batch of this shape into -- out4 = {pieces per target (merge), shortest stretch worth a
  * piece, 1 when the four-segments-per-wave merge kernel takes the batch, pieces per target (bestPath)}.

@@ -30,7 +30,7 @@ EXPORTS = [
     "dagcon_last_error", "dagcon_consensus", "dagcon_upload", "dagcon_run", "dagcon_sync",
     "dagcon_fetch", "dagcon_get_timings", "dagcon_normalize", "dagcon_debug_graph",
     "dagcon_debug_counters", "dagcon_host_alloc", "dagcon_host_free", "dagcon_align",
-    "dagcon_consensus_pre", "dagcon_debug_plan",
+    "dagcon_consensus_pre", "dagcon_debug_plan", "dagcon_align_dropped",
 ]
 ABI_VERSION = 2
 

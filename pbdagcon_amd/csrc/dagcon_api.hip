@@ -99,6 +99,7 @@ struct Ctx {
     uint32_t max_len = 0, bs_stride = 0;
     DevBuf d_matK, d_bbstart;
     int bp_fused = 1;                              // partial-span bestPath: one (A, B) sweep + vertex-parallel kernels (DAGCON_BP_FUSED=0: three sweeps)
+    uint32_t align_dropped = 0;                    // records of the last dagcon_align / dagcon_consensus_pre the band could not align
     int fold = 1;                                  // duplicate insertion chains folded by k_emit (DAGCON_FOLD=0: never)
     int merge_q = 1, use_q = 0;                    // k_merge_q: four segments per wave (DAGCON_MERGE_Q=0: never); this batch
     uint32_t max_k = 0, max_tlen = 0;
@@ -891,6 +892,10 @@ int dagcon_debug_counters(dagcon_ctx *ctx, unsigned long long *out8) {
     return DAGCON_OK;
 }
 
+uint32_t dagcon_align_dropped(dagcon_ctx *ctx) {
+    return ctx ? reinterpret_cast<Ctx *>(ctx)->align_dropped : 0u;
+}
+
 // host arithmetic only (no device, no context): the pieces a batch of that shape would be cut into
 int dagcon_debug_plan(uint32_t n_targets, uint64_t n_alignments, uint64_t sum_positions, uint32_t partial_span,
                       uint32_t max_segments, uint32_t min_segment_len, uint32_t out4[4]) {
@@ -1171,8 +1176,14 @@ static int align_device(Ctx *c, uint32_t n, const uint64_t *q_off, const uint32_
         }
     }
     HIPCHK(c, d2h(c, aln_len, dlen.p, (size_t)n * 4));
-    for (uint32_t a = 0; a < n; a++)
+    uint32_t dropped = 0;
+    for (uint32_t a = 0; a < n; a++) {
         if ((uint64_t)aln_len[a] > (uint64_t)q_len[a] + t_len[a]) return fail(c, DAGCON_ERR_INTERNAL, "pair %u: alignment longer than its room", a);
+        // the band could not connect the corners (sequences of very different lengths, indels beyond the widest band):
+        // length 0, and the record then falls to the min_len filter -- the reference's SDPAlign always returns something
+        dropped += aln_len[a] == 0 && (q_len[a] || t_len[a]);
+    }
+    c->align_dropped = dropped;                   // (the call succeeds: dagcon_align_dropped reports them)
     *out_bytes_ret = out_bytes;
     return DAGCON_OK;
 }

@@ -229,6 +229,8 @@ int flush(dagcon_ctx *ctx, Batch &b, const Opts &o, Blob *scratch) {
             fprintf(stderr, "pbdagcon: alignment / consensus failed (%d): %s\n", rc, dagcon_last_error(ctx));
             return 1;
         }
+        if (const uint32_t nd = dagcon_align_dropped(ctx))
+            fprintf(stderr, "pbdagcon: warning: %u of %zu records could not be aligned inside the widest band and were dropped\n", nd, A);
         have_results = true;
     } else if (o.align) {
         const double ta0 = wall();
@@ -247,6 +249,8 @@ int flush(dagcon_ctx *ctx, Batch &b, const Opts &o, Blob *scratch) {
             fprintf(stderr, "pbdagcon: alignment failed (%d): %s\n", rc, dagcon_last_error(ctx));
             return 1;
         }
+        if (const uint32_t nd = dagcon_align_dropped(ctx))
+            fprintf(stderr, "pbdagcon: warning: %u of %zu records could not be aligned inside the widest band and were dropped\n", nd, A);
         size_t g = 0;
         for (size_t a = 0; a < A; a++) {
             while (b.begin[g + 1] <= a) g++;
@@ -705,7 +709,7 @@ int main(int argc, char **argv) {
                                               memcmp(recs[x]->id, recs[x - 1]->id, recs[x]->idl) != 0);
             // a batch is closed when it is full, and at the end of the slab's usable records once it
             // holds something (at the end of the input whatever it holds)
-            if (last || (new_target && x > rb && (b.ids.size() >= o.batch_targets || bytes >= o.batch_bytes))) {
+            if (last || (new_target && x > rb && (b.ids.size() >= o.batch_targets || bytes + bytes2 >= o.batch_bytes))) {   // (-a: the t strings count too)
                 if (x > rb) {
                     b.begin.push_back(b.start.size());
                     { const double t0 = now(); fill_strings(b, rb, x, bytes, bytes2); t_fill += now() - t0; }

@@ -1122,3 +1122,24 @@ def test_one_deep_target_in_a_shallow_batch(gpu_ctx_factory):
     assert tm["ms_total"] < 2.0 * ms_sh + 1500.0, \
         f"mixed batch {tm['ms_total']:.1f} ms (merge {tm['ms_merge']:.1f}) against {ms_sh:.1f} ms for the 999 shallow targets alone"
     print(f"mixed-coverage batch: {tm['ms_total']:.1f} ms (merge {tm['ms_merge']:.1f} ms); shallow alone {ms_sh:.1f} ms")
+
+
+def test_align_reports_the_records_it_drops(gpu_ctx_factory):
+    """A pair whose corners no band connects (a 12-base read against a 9 kb target: the band moves 750 columns a row) comes back with length 0, as
+    from the CPU twin; where the reference's SDPAlign + GuidedAlign would return something (SimpleAligner.cpp:35-48) the
+    record is then dropped by the min_len filter -- dagcon_align_dropped says how many (the CLI warns)."""
+    import ctypes
+    rng = np.random.default_rng(5)
+    t_long = bytes(b"ACGT"[k] for k in rng.integers(0, 4, 9000))
+    ok_t = bytes(b"ACGT"[k] for k in rng.integers(0, 4, 700))
+    pairs = [(ok_t[:650], ok_t), (t_long[:12], t_long), (ok_t, ok_t)]
+    ctx = gpu_ctx_factory(min_cov=0, min_len=0, trim=0)
+    got = ctx.align(pairs)
+    exp = [oracle.banded_align(q, t) for q, t in pairs]
+    assert got == exp
+    assert len(got[1][0]) == 0 and len(got[0][0]) > 0 and len(got[2][0]) == 700
+    ctx.L.dagcon_align_dropped.restype = ctypes.c_uint32
+    ctx.L.dagcon_align_dropped.argtypes = [ctypes.c_void_p]
+    assert ctx.L.dagcon_align_dropped(ctx.h) == 1
+    ctx.align(pairs[:1])
+    assert ctx.L.dagcon_align_dropped(ctx.h) == 0
