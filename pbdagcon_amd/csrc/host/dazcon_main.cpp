@@ -13,7 +13,10 @@
 //   nextTarget's filters                            DazAlnProvider.cpp:79-117  (target list, min coverage)
 //   Consensus / record format                       dazcon.cpp:61-107 (real backbone, -t 10, ">%s/%d/%d_%d")
 //
-// with the reference's flags and defaults (dazcon.cpp:122-192).  -s names a text file that carries what
+// with the reference's flags and defaults (dazcon.cpp:122-192).  Round 3: -a <file>.las and -s <file>.db are read in
+// their binary layouts (daz_io.h: PARITY UNPINNED, tested by round trip against this build's own writer), and every
+// overlap of a .las is aligned between its end points by the device aligner (dagcon_align) where the reference runs
+// DALIGNER's Compute_Trace_PTS.  Otherwise -s names a text file that carries what
 // the .db holds (the reads) and -a one that carries what the .las holds after Read_Overlap /
 // Compute_Trace_PTS (overlap records with their trace points, or with alignment strings already
 // decoded); INTEGRATION.md gives the layout:
@@ -43,6 +46,7 @@
 #include <vector>
 
 #include "../../../include/dagcon.h"
+#include "daz_io.h"
 
 namespace {
 
@@ -60,8 +64,8 @@ void usage(FILE *f) {
     fprintf(f,
             "USAGE: dazcon -a <overlaps> -s <reads> [-j <int>] [-c <uint>] [-l <uint>] [-t <uint>] [-m <uint>] [-x] [-o] [-v] [targets ...]\n"
             "  PBI consensus module (DAGCon over daligner-style overlaps); the consensus runs on an MI355X.\n"
-            "  -a, --align-file    overlap records (text layout: see INTEGRATION.md; .las needs DALIGNER, not in this build)\n"
-            "  -s, --seq-file      reads (text layout; .db needs DAZZ_DB, not in this build)\n"
+            "  -a, --align-file    overlaps: a DALIGNER .las file (name ends in .las), or the text layout of INTEGRATION.md\n"
+            "  -s, --seq-file      reads: a DAZZ_DB database (name ends in .db; its .idx / .bps beside it), or the text layout\n"
             "  -j, --threads       accepted for compatibility (default 4); the consensus is the GPU's\n"
             "  -c, --min-coverage  minimum coverage for correction (default 6)\n"
             "  -l, --min-len       minimum length for correction (default 500)\n"
@@ -132,6 +136,7 @@ struct Record {
     unsigned flags = 0;
     Path path;
     bool decoded = false;              // O record: strings given
+    bool realign = false;              // .las record: aligned between its end points on the device (see daz_io.h)
     std::string tstr, qstr;
     std::vector<int> trace;            // R record: what Compute_Trace_PTS left in path.trace
 };
@@ -237,7 +242,7 @@ std::string complement_seq(const std::string &s) {        // DAZZ_DB Complement_
     return r;
 }
 
-struct Aln { unsigned start; std::string q, t; };
+struct Aln { unsigned start; std::string q, t; bool job = false; int aread = 0, bread = 0; unsigned flags = 0; Path path; };
 struct TargetData { int id; std::string seq; std::vector<Aln> alns; };
 
 }  // namespace
@@ -245,9 +250,19 @@ struct TargetData { int id; std::string seq; std::vector<Aln> alns; };
 int main(int argc, char **argv) {
     Opts o;
     if (int rc = parse_args(argc, argv, o)) return rc;
+    auto ends_with = [](const std::string &x, const char *suf) { const size_t n = strlen(suf); return x.size() >= n && x.compare(x.size() - n, n, suf) == 0; };
+    const bool las_in = ends_with(o.aln_file, ".las"), db_in = ends_with(o.seq_file, ".db");
     // ---- reads (-s) ----
     std::vector<std::string> reads;       // index = 0-based read id
-    {
+    if (db_in) {
+        // Open_DB + Trim_DB (DazAlnProvider.cpp:34-41); every read as ToU[Load_Subread(...)] would give it (:125-130)
+        daz::Db db;
+        std::string err;
+        if (!db.open(o.seq_file, &err)) { fprintf(stderr, "dazcon: %s\n", err.c_str()); return 1; }
+        db.trim();
+        reads.resize(db.size());
+        for (size_t i = 0; i < db.size(); i++) reads[i] = db.read(i);
+    } else {
         std::ifstream in(o.seq_file);
         if (!in) { fprintf(stderr, "dazcon: error opening sequence file: %s\n", o.seq_file.c_str()); return 1; }
         std::string line;
@@ -261,9 +276,13 @@ int main(int argc, char **argv) {
         }
     }
     // ---- overlaps (-a), grouped by A-read as DazAlnProvider::nextTarget does (:79-117) ----
-    std::ifstream in(o.aln_file);
-    if (!in) { fprintf(stderr, "dazcon: error opening alignment file: %s\n", o.aln_file.c_str()); return 1; }
+    std::ifstream in;
+    if (!las_in) {
+        in.open(o.aln_file);
+        if (!in) { fprintf(stderr, "dazcon: error opening alignment file: %s\n", o.aln_file.c_str()); return 1; }
+    }
     std::vector<TargetData> out_targets;
+    size_t n_jobs = 0;
     Target trg;
     auto finish_target = [&]() -> int {
         if (trg.id < 0) return 0;
@@ -282,6 +301,7 @@ int main(int argc, char **argv) {
                 Aln al;
                 al.start = (unsigned)rec.path.abpos + 1;                                 // :358
                 if (rec.decoded) { al.t = rec.tstr; al.q = rec.qstr; }
+                else if (rec.realign) { al.job = true; al.aread = rec.aread; al.bread = rec.bread; al.flags = rec.flags; al.path = rec.path; n_jobs++; }
                 else {
                     if ((size_t)rec.bread >= reads.size() || reads[(size_t)rec.bread].empty()) {
                         fprintf(stderr, "dazcon: read %d is not in %s\n", rec.bread + 1, o.seq_file.c_str());
@@ -293,14 +313,55 @@ int main(int argc, char **argv) {
                 td.alns.push_back(std::move(al));
             }
         }
-        if (td.alns.size() < o.min_cov) return 0;                                      // :98-101
-        if (o.dump_alns)
-            for (const Aln &al : td.alns) printf("%d\t%u\t%s\t%s\n", tid, al.start, al.t.c_str(), al.q.c_str());
+        if (td.alns.size() < o.min_cov) { for (const Aln &al : td.alns) n_jobs -= al.job; return 0; }   // :98-101
         td.seq = reads[(size_t)trg.id];                                                // :119-132 (the A-read itself)
         out_targets.push_back(std::move(td));
         return 0;
     };
-    {
+    // a record joins its target (DazAlnProvider::nextTarget, :79-117); `where` names it in messages
+    auto take = [&](Record &&r, const std::string &where) -> int {
+        if (r.aread < 0 || (size_t)r.aread >= reads.size() || reads[(size_t)r.aread].empty()) {
+            fprintf(stderr, "dazcon: read %d is not in %s\n", r.aread + 1, o.seq_file.c_str());
+            return 1;
+        }
+        if (r.path.abpos < 0 || r.path.aepos < r.path.abpos || r.path.aepos > (int)reads[(size_t)r.aread].size()) {
+            fprintf(stderr, "dazcon: %s: A interval outside the read\n", where.c_str());
+            return 1;
+        }
+        if (r.realign) {
+            if (r.bread < 0 || (size_t)r.bread >= reads.size() || r.path.bbpos < 0 || r.path.bepos < r.path.bbpos ||
+                r.path.bepos > (int)reads[(size_t)r.bread].size()) {
+                fprintf(stderr, "dazcon: %s: B read or interval outside the database\n", where.c_str());
+                return 1;
+            }
+        }
+        if (r.aread != trg.id) {                                                     // :90: the A-read changes
+            if (int rc = finish_target()) return rc;
+            trg = Target();
+            trg.id = r.aread;                                                        // firstRecord (:229-249)
+            trg.length = (int)reads[(size_t)r.aread].size();
+        }
+        const int blen = (size_t)r.bread < reads.size() ? (int)reads[(size_t)r.bread].size() : 0;
+        trg.addRecord(std::move(r), blen, o.proper);
+        return 0;
+    };
+    if (las_in) {
+        // Read_Overlap / Read_Trace (DazAlnProvider.cpp:134-140); the trace points are read and passed over: the
+        // alignment between the overlap's end points is the device aligner's (daz_io.h)
+        daz::LasReader las;
+        std::string err;
+        if (!las.open(o.aln_file, &err)) { fprintf(stderr, "dazcon: %s\n", err.c_str()); return 1; }
+        daz::Overlap ov;
+        std::vector<uint16_t> tr;
+        while (las.next(&ov, &tr, &err)) {
+            Record r;
+            r.aread = ov.aread; r.bread = ov.bread; r.flags = ov.flags; r.realign = true;
+            r.path.abpos = ov.abpos; r.path.aepos = ov.aepos; r.path.bbpos = ov.bbpos; r.path.bepos = ov.bepos; r.path.diffs = ov.diffs;
+            if (int rc = take(std::move(r), "overlap " + std::to_string(las.seen))) return rc;
+        }
+        if (!err.empty()) { fprintf(stderr, "dazcon: %s\n", err.c_str()); return 1; }
+        if (int rc = finish_target()) return rc;
+    } else {
         std::string line;
         unsigned long long ln = 0;
         while (std::getline(in, line)) {
@@ -335,26 +396,16 @@ int main(int argc, char **argv) {
                     }
                 }
             }
-            if ((size_t)r.aread >= reads.size() || reads[(size_t)r.aread].empty()) {
-                fprintf(stderr, "dazcon: read %d is not in %s\n", r.aread + 1, o.seq_file.c_str());
-                return 1;
-            }
-            if (r.path.abpos < 0 || r.path.aepos < r.path.abpos || r.path.aepos > (int)reads[(size_t)r.aread].size()) {
-                fprintf(stderr, "dazcon: line %llu: A interval outside the read\n", ln);
-                return 1;
-            }
-            if (r.aread != trg.id) {                                                     // :90: the A-read changes
-                if (int rc = finish_target()) return rc;
-                trg = Target();
-                trg.id = r.aread;                                                        // firstRecord (:229-249)
-                trg.length = (int)reads[(size_t)r.aread].size();
-            }
-            const int blen = (size_t)r.bread < reads.size() ? (int)reads[(size_t)r.bread].size() : 0;
-            trg.addRecord(std::move(r), blen, o.proper);
+            if (int rc = take(std::move(r), "line " + std::to_string(ln))) return rc;
         }
         if (int rc = finish_target()) return rc;
     }
-    if (o.dump_hits || o.dump_alns) return 0;
+    if (o.dump_hits) return 0;
+    if (o.dump_alns && !n_jobs) {
+        for (const TargetData &td : out_targets)
+            for (const Aln &al : td.alns) printf("%d\t%u\t%s\t%s\n", td.id, al.start, al.t.c_str(), al.q.c_str());
+        return 0;
+    }
 
     // ---- Consensus (dazcon.cpp:61-107) on the device, batches of targets, real backbones ----
     dagcon_ctx *ctx = nullptr;
@@ -367,6 +418,50 @@ int main(int argc, char **argv) {
     if (rc != DAGCON_OK) {
         fprintf(stderr, "dazcon: no usable MI355X as device %d (dagcon_create = %d); there is no CPU fallback\n", o.device, rc);
         return 1;
+    }
+    if (n_jobs) {
+        // the overlaps of a .las: A[abpos, aepos) against B[bbpos, bepos) (B complemented when COMP(flags), its
+        // coordinates are the complement's: DazAlnProvider.cpp:333-347), global between the end points, in groups of
+        // at most 256 MB of sequence
+        std::vector<Aln *> jobs;
+        for (TargetData &td : out_targets) for (Aln &al : td.alns) if (al.job) jobs.push_back(&al);
+        size_t j0 = 0;
+        uint32_t dropped = 0;
+        while (j0 < jobs.size()) {
+            std::string qb, tb;
+            std::vector<uint64_t> qo, to, oo;
+            std::vector<uint32_t> ql, tl;
+            uint64_t room = 0;
+            size_t j1 = j0;
+            for (; j1 < jobs.size() && qb.size() + tb.size() < (256u << 20); j1++) {
+                const Aln &al = *jobs[j1];
+                const std::string &bs = reads[(size_t)al.bread];
+                const std::string bq = (al.flags & daz::COMP_FLAG) ? complement_seq(bs) : bs;
+                qo.push_back(qb.size()); ql.push_back((uint32_t)(al.path.bepos - al.path.bbpos));
+                qb.append(bq, (size_t)al.path.bbpos, (size_t)(al.path.bepos - al.path.bbpos));
+                to.push_back(tb.size()); tl.push_back((uint32_t)(al.path.aepos - al.path.abpos));
+                tb.append(reads[(size_t)al.aread], (size_t)al.path.abpos, (size_t)(al.path.aepos - al.path.abpos));
+                oo.push_back(room); room += (uint64_t)ql.back() + tl.back();
+            }
+            std::string qa((size_t)room + 1, '\0'), ta((size_t)room + 1, '\0');
+            std::vector<uint32_t> alen(j1 - j0, 0);
+            rc = dagcon_align(ctx, (uint32_t)(j1 - j0), qo.data(), ql.data(), to.data(), tl.data(), qb.data(), qb.size(), tb.data(), tb.size(),
+                              oo.data(), &qa[0], &ta[0], alen.data());
+            if (rc != DAGCON_OK) { fprintf(stderr, "dazcon: alignment failed (%d): %s\n", rc, dagcon_last_error(ctx)); dagcon_destroy(ctx); return 1; }
+            dropped += dagcon_align_dropped(ctx);
+            for (size_t j = j0; j < j1; j++) {
+                jobs[j]->q.assign(qa, (size_t)oo[j - j0], alen[j - j0]);
+                jobs[j]->t.assign(ta, (size_t)oo[j - j0], alen[j - j0]);
+            }
+            j0 = j1;
+        }
+        if (dropped) fprintf(stderr, "dazcon: warning: %u overlaps could not be aligned inside the widest band and were dropped\n", dropped);
+        if (o.dump_alns) {
+            for (const TargetData &td : out_targets)
+                for (const Aln &al : td.alns) printf("%d\t%u\t%s\t%s\n", td.id, al.start, al.t.c_str(), al.q.c_str());
+            dagcon_destroy(ctx);
+            return 0;
+        }
     }
     int fake_well_counter = 0;                     // dazcon.cpp:62 reads it uninitialised (Q4)
     int status = 0;

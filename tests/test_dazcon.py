@@ -132,3 +132,111 @@ def test_dazcon_end_to_end(tmp_path):
             exp.append(b">%d/%d/%d_%d\n%s\n" % (aid, well, r0, r1, s))
             well += 1
     assert out.stdout == b"".join(exp) and len(exp) >= 4
+
+
+# ---- round 3: the binary inputs (.las / .db) -- PARITY UNPINNED, round trip against this build's own writer ----------
+
+def _las_case(tmp_path, rng, n_targets=3, cov=10, tlen=1500, tspace=100, comp=True):
+    """Reads + overlaps: every target read gets `cov` B reads cut from it (mutated, some reverse-complemented)."""
+    import daz_files
+    rc = str.maketrans("ACGT", "TGCA")
+    seq = lambda n: "".join("ACGT"[k] for k in rng.integers(0, 4, n))
+
+    def mutate(s):
+        out = []
+        for ch in s:
+            u = rng.random()
+            if u < 0.04:
+                continue
+            out.append(ch if u > 0.07 else "ACGT"[rng.integers(0, 4)])
+            if rng.random() < 0.05:
+                out.append("ACGT"[rng.integers(0, 4)])
+        return "".join(out)
+
+    reads, ovl = [], []
+    for t in range(n_targets):
+        a = seq(tlen + int(rng.integers(0, 300)))
+        ai = len(reads)
+        reads.append(a)
+        for k in range(cov):
+            s = int(rng.integers(0, len(a) // 3)); e = int(rng.integers(2 * len(a) // 3, len(a) + 1))
+            b = mutate(a[s:e])
+            flank_l, flank_r = seq(int(rng.integers(0, 40))), seq(int(rng.integers(0, 40)))
+            whole = flank_l + b + flank_r
+            fl = int(comp and rng.random() < 0.5)
+            bi = len(reads)
+            # COMP overlaps: the B read is stored reverse-complemented, bbpos / bepos are the complement's coordinates
+            reads.append(whole.translate(rc)[::-1] if fl else whole)
+            ovl.append(dict(aread=ai, bread=bi, flags=fl, abpos=s, aepos=e, bbpos=len(flank_l), bepos=len(flank_l) + len(b),
+                            diffs=int(0.1 * (e - s))))
+    db, las = str(tmp_path / "reads.db"), str(tmp_path / "ovl.las")
+    daz_files.write_db(db, reads)
+    daz_files.write_las(las, ovl, tspace)
+    return reads, ovl, db, las
+
+
+@pytest.mark.parametrize("tspace", [100, 500])
+def test_las_db_readers_round_trip(tmp_path, tspace):
+    """daz_io.h against tests/daz_files.py: a database and a .las written here are read back read by read and overlap
+    by overlap (the hit dump: A read, B read, flags, scores from the path fields) -- the same dump as the text
+    layout of the same records gives; one-byte (tspace 100) and two-byte (tspace 500 > TRACE_XOVR) trace elements; a
+    database that Trim_DB renumbers (cutoff, not `all`)."""
+    import daz_files
+    rng = np.random.default_rng(3 + tspace)
+    reads, ovl, db, las = _las_case(tmp_path, rng, tspace=tspace)
+    out = subprocess.run([_cli(), "-a", las, "-s", db, "--dump-hits", "-c", "0"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    lines = [f"O {o['aread'] + 1} {o['bread'] + 1} {o['flags']} {o['abpos']} {o['aepos']} {o['bbpos']} {o['bepos']} {o['diffs']} A A" for o in ovl]
+    txt = subprocess.run([_cli(), *_write(tmp_path, {i + 1: s for i, s in enumerate(reads)}, lines), "--dump-hits", "-c", "0"],
+                         capture_output=True, text=True)
+    assert txt.returncode == 0 and out.stdout == txt.stdout and len(out.stdout.splitlines()) == len(ovl)
+    # Trim_DB: reads below the cutoff and reads that are not their well's best are gone, the rest renumbered
+    flags = [daz_files.DB_BEST] * len(reads)
+    extra = reads[:1] + ["ACGT" * 5] + reads[1:]                       # a 20-base read in second place
+    flags2 = [daz_files.DB_BEST, daz_files.DB_BEST] + flags[1:]
+    extra.append("ACGT" * 400); flags2.append(0)                        # a long read that is not the best of its well
+    daz_files.write_db(db, extra, cutoff=100, all_=0, flags=flags2)
+    out2 = subprocess.run([_cli(), "-a", las, "-s", db, "--dump-hits", "-c", "0"], capture_output=True, text=True)
+    assert out2.returncode == 0 and out2.stdout == out.stdout
+    # damaged files are refused
+    open(las, "r+b").truncate(os.path.getsize(las) - 7)
+    assert subprocess.run([_cli(), "-a", las, "-s", db, "--dump-hits"], capture_output=True).returncode == 1
+    assert subprocess.run([_cli(), "-a", str(tmp_path / "none.las"), "-s", db, "--dump-hits"], capture_output=True).returncode == 1
+    os.unlink(str(tmp_path / ".reads.idx"))
+    assert subprocess.run([_cli(), "-a", las, "-s", db, "--dump-hits"], capture_output=True).returncode == 1
+
+
+@pytest.mark.gpu
+def test_dazcon_on_las_and_db(tmp_path):
+    """dazcon on a .las + .db pair (BASELINE configs[4]'s input surface): every overlap aligned between its end points
+    on the device (where the reference runs DALIGNER's Compute_Trace_PTS: absent, parity unpinned), then the dazcon path
+    as before.  The same run composed on the CPU -- the twin aligner on A[abpos, aepos) x B'[bbpos, bepos), hit selection
+    by the model, the oracle's real-backbone consensus -- gives the same FASTA byte for byte."""
+    import oracle
+    rng = np.random.default_rng(17)
+    reads, ovl, db, las = _las_case(tmp_path, rng, n_targets=4, cov=12, tlen=2500)
+    out = subprocess.run([_cli(), "-a", las, "-s", db, "-c", "4", "-l", "500"], capture_output=True)
+    assert out.returncode == 0, out.stderr.decode()
+    rc = bytes.maketrans(b"ACGT", b"TGCA")
+    exp, well = [], 0
+    by_a = {}
+    for o in ovl:
+        by_a.setdefault(o["aread"], []).append(o)
+    for ai in sorted(by_a):
+        a = reads[ai].encode()
+        hits = dm.group_hits(by_a[ai], len(a), {o["bread"]: len(reads[o["bread"]]) for o in by_a[ai]})
+        hits = dm.sort_hits(hits, len(a), False)[:85]
+        alns = []
+        for h in hits:
+            for r in h.records:
+                b = reads[r["bread"]].encode()
+                if r["flags"] & 1:
+                    b = b.translate(rc)[::-1]
+                qa, ta = oracle.banded_align(b[r["bbpos"]:r["bepos"]], a[r["abpos"]:r["aepos"]])
+                alns.append((r["abpos"] + 1, qa, ta))
+        if len(alns) < 4:
+            continue
+        for r0, r1, sq in oracle.consensus_target(len(a), alns, 500, 10, 4, backbone=a):
+            exp.append(b">%d/%d/%d_%d\n%s\n" % (ai + 1, well, r0, r1, sq))
+            well += 1
+    assert len(exp) >= 3 and out.stdout == b"".join(exp)
