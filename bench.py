@@ -172,13 +172,22 @@ def rehearse(args, rank, world):
 def raw_fasta(ids, raw):
     """FASTA records (main.cpp:141-143) straight from a dagcon_results struct."""
     import ctypes as C
+    import numpy as np
     blob = C.string_at(raw.seq_blob, raw.seq_bytes) if raw.seq_bytes else b""
+    T, S = raw.n_targets, raw.n_segments
+    if not S:
+        return b""
+    begin = np.ctypeslib.as_array(raw.seg_begin, (T + 1,)).tolist()
+    r0 = np.ctypeslib.as_array(raw.range0, (S,)).tolist()
+    r1 = np.ctypeslib.as_array(raw.range1, (S,)).tolist()
+    off = np.ctypeslib.as_array(raw.seq_off, (S,)).tolist()
+    ln = np.ctypeslib.as_array(raw.seq_len, (S,)).tolist()
     out = []
-    for t in range(raw.n_targets):
-        tid = ids[t].encode()
-        for s in range(raw.seg_begin[t], raw.seg_begin[t + 1]):
-            o, n = raw.seq_off[s], raw.seq_len[s]
-            out.append(b">%s/%d_%d\n%s\n" % (tid, raw.range0[s], raw.range1[s], blob[o:o + n]))
+    for t in range(T):
+        for s in range(begin[t], begin[t + 1]):
+            out.append(b">%s/%d_%d\n" % (ids[t], r0[s], r1[s]))
+            out.append(blob[off[s]:off[s] + ln[s]])
+            out.append(b"\n")
     return b"".join(out)
 
 
@@ -247,7 +256,7 @@ def stream_plan(total, per_batch, world, tlen, coverage):
 
 
 def target_ids(first, n, tlen):
-    return ["t%07d/0_%d" % (first + k, tlen) for k in range(n)]
+    return [b"t%07d/0_%d" % (first + k, tlen) for k in range(n)]
 
 
 def fake_records(first, n, tlen):
@@ -316,7 +325,7 @@ def stream_worker(args, rank, world, local_rank, quiet=False):
     keep_first = {}
 
     def seqs_only(fa):
-        return hashlib.sha256(b"\n".join(l for l in fa.split(b"\n") if not l.startswith(b">"))).digest()
+        return hashlib.sha256(b"\n".join(fa.split(b"\n")[1::2])).digest()       # (every record is a header line and a sequence line)
 
     gathered_parts = [[] for _ in range(world)]
     state = {"done": 0, "round": 0, "sent": 0}
@@ -339,9 +348,11 @@ def stream_worker(args, rank, world, local_rank, quiet=False):
                 gathered_parts[r].append(out[pos:pos + n])
                 pos += n
 
+    all_ids = [target_ids(f, n, args.tlen) for f, n in mine]
+
     def on_result(i, raw):
         f, n = mine[i]
-        fa = raw_fasta(target_ids(f, n, args.tlen), raw)
+        fa = raw_fasta(all_ids[i], raw)
         parts.append(fa)
         if n == distinct[i % nd].n_targets:
             d = seqs_only(fa)

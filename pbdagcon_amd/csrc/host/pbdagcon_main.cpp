@@ -64,6 +64,8 @@ void usage(FILE *f) {
             "  -m, --min-length    minimum alignment / consensus length (default 500)\n"
             "  -t, --trim          trim alignments on either side (default 50)\n"
             "  -a, --align         input is .pre (qid tid strand tlen tstart tend qseq tseq): align the sequences first\n"
+            "                      (this build's own banded GLOBAL aligner on the GPU; the reference's blasr SDPAlign(Local) +\n"
+            "                      GuidedAlign is not in its tree: parity unpinned beyond its one SimpleAligner known-answer test)\n"
             "  -v, --verbose       per-target progress on stderr\n"
             "  --polish N          with -a: N more rounds, each with the previous round's consensus as the backbone the reads\n"
             "                      are re-aligned to (README.md:14-15 of the reference: 'the new consensus can be used as a new\n"
