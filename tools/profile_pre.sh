@@ -9,6 +9,7 @@ mkdir -p $OUT
 E2E_KEEP=1 python3 $R/tools/e2e_pre.py 64 50000 60 > $OUT/e2e.log 2>&1
 F=/dev/shm/e2e.pre
 cd /tmp; export TMPDIR=/tmp
+export PBDAGCON_TEARDOWN=1      # (the profiler writes its files from exit handlers: the command line must end in order)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ks -o ks -- $R/pbdagcon_amd/bin/pbdagcon -a -c 8 -j 16 $F > $OUT/out.fa 2> $OUT/ks.log
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU --output-format csv -d $OUT/insts -o insts -- $R/pbdagcon_amd/bin/pbdagcon -a -c 8 -j 16 $F > /dev/null 2> $OUT/insts.log
 rm -f $F $OUT/out.fa
