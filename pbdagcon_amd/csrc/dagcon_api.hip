@@ -100,6 +100,7 @@ struct Ctx {
     DevBuf d_matK, d_bbstart;
     int bp_fused = 1;                              // partial-span bestPath: one (A, B) sweep + vertex-parallel kernels (DAGCON_BP_FUSED=0: three sweeps)
     uint32_t align_dropped = 0;                    // records of the last dagcon_align / dagcon_consensus_pre the band could not align
+    int emit_scan = 1;                             // k_emit takes the prefix over the reads itself (DAGCON_EMIT_SCAN=0: k_groups, as for deeper targets)
     int fold = 1;                                  // duplicate insertion chains folded by k_emit (DAGCON_FOLD=0: never)
     int merge_q = 1, use_q = 0;                    // k_merge_q: four segments per wave (DAGCON_MERGE_Q=0: never); this batch
     uint32_t max_k = 0, max_tlen = 0;
@@ -302,6 +303,7 @@ void fill_params(Ctx *c, DgParams &p) {
 #endif
     p.emit2 = c->emit2 ? 1u : 0u; p.matK = (uint8_t *)c->d_matK.p; p.bbstart = (uint32_t *)c->d_bbstart.p; p.bs_stride = c->bs_stride;
     p.bp_fused = c->bp_fused ? 1u : 0u; p.score_b = (float *)c->d_score_b.p;
+    p.emit_scan = (c->emit_scan && c->max_k <= 64u && !c->emit2) ? 1u : 0u;
     p.fold = (c->fold && !(c->opts.flags & DAGCON_FLAG_STOP_AFTER_BUILD)) ? 1u : 0u;
     p.q_kmax = c->use_q && !c->opts.max_segments && !c->seg_env && c->max_k > DQ_KMAX ? DQ_KMAX : 0u;
     p.seg_max = c->seg_max; p.seg_min = c->seg_min; p.cuts = (uint32_t *)c->d_cuts.p; p.bp_max = c->bp_max; p.cuts_bp = (uint32_t *)c->d_cuts_bp.p; p.bp_stat = (float *)c->d_bp_stat.p; p.bp_len = (uint32_t *)c->d_bp_len.p;
@@ -352,7 +354,8 @@ int launch_all(Ctx *c) {
     if (c->T > 0) {
         const uint32_t rows4 = (c->max_tlen + 2 + 4 * DG_LPW - 1) / (4 * DG_LPW);   // 4 waves x DG_LPW positions per block
         if (c->gcuts && c->A > 0) hipLaunchKernelGGL(k_readspan, dim3((c->A + 63) / 64), dim3(64), 0, s, p);   // (before matC becomes prefix sums)
-        hipLaunchKernelGGL(k_groups, dim3(c->T, (c->max_tlen + 2 + 31) / 32), dim3(256), 0, s, p);
+        if (p.emit_scan) hipLaunchKernelGGL(k_gsum, dim3(c->T, (c->max_tlen + 2 + 255) / 256), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL(k_groups, dim3(c->T, (c->max_tlen + 2 + 31) / 32), dim3(256), 0, s, p);
         hipLaunchKernelGGL(k_gscan, dim3(c->T), dim3(1024), 0, s, p);
 #ifdef DG_EXPERIMENTS
         if (c->A > 0 && c->emit2) {
@@ -470,6 +473,7 @@ int dagcon_create(const dagcon_opts *opts, dagcon_ctx **out) {
         if (v >= 1 && v <= 64) c->seg_env = (uint32_t)v;
     }
     if (const char *e = getenv("DAGCON_FOLD")) c->fold = atoi(e) != 0;
+    if (const char *e = getenv("DAGCON_EMIT_SCAN")) c->emit_scan = atoi(e) != 0;
     if (const char *e = getenv("DAGCON_BP_FUSED")) c->bp_fused = atoi(e) != 0;
 #ifdef DG_EXPERIMENTS
     if (const char *e = getenv("DAGCON_EMIT2")) c->emit2 = atoi(e) != 0;

@@ -169,6 +169,8 @@ struct DgParams {
     uint32_t stk_words;
     uint32_t growth_pct;           // pool growth region as % of the initial adjacency words
     uint32_t pf_ahead;             // vertices the prefetch wave runs ahead of the sweep (0 = off)
+    uint32_t emit_scan;            // 1 (every target has at most 64 reads): matC keeps the insertion run lengths, k_gsum adds them up
+                                   // per position (gcount) and k_emit takes the prefix over the reads itself (DPP): no k_groups
     uint32_t fold;                 // 1: k_emit folds duplicate insertion chains as it builds (dg_emit_fold); 0 with
                                    // DAGCON_FLAG_STOP_AFTER_BUILD (the dump is then addAln's graph itself) and DAGCON_FOLD=0
     uint32_t q_kmax;               // k_merge_q takes the targets of at most this many reads, k_merge the deeper ones (0: no split)

@@ -841,6 +841,38 @@ __device__ __forceinline__ bool dg_emit_fold(unsigned long long em, const uint32
     return victim;
 }
 
+// exclusive prefix sum over the lanes of a wave: four DPP row shifts inside the rows of 16 lanes, two row broadcasts
+// across them (lanes without a source add 0); no LDS
+__device__ __forceinline__ uint32_t dg_wave_excl(const uint32_t v, const int lane) {
+    int incl = (int)v;
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xf, 0xf, false);     // row_shr:1
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xf, 0xf, false);     // row_shr:2
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xf, 0xf, false);     // row_shr:4
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xf, 0xf, false);     // row_shr:8
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x142, 0xa, 0xf, false);     // row_bcast:15 into rows 1 and 3
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x143, 0xc, 0xf, false);     // row_bcast:31 into rows 2 and 3
+    (void)lane;
+    return (uint32_t)incl - v;
+}
+
+// ---------------------------------------------------------------------------
+// k_gsum (p.emit_scan): gcount[p] = inserted vertices whose _bbMap is p = the column sum of the reads' run lengths; a
+// thread per position, the reads' rows read side by side (k_groups does the same and the prefix over the reads with it,
+// in place: where every target has at most a wave of reads k_emit takes that prefix itself)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gsum(DgParams p) {
+    const uint32_t t = blockIdx.x;
+    if (dg_failed(p) || dg_tskip(p, t)) return;
+    const uint32_t pos = blockIdx.y * 256u + threadIdx.x;
+    if (pos >= p.tlen[t] + 2u) return;
+    const uint32_t K = (uint32_t)(p.aln_begin[t + 1] - p.aln_begin[t]);
+    const uint32_t *col = p.matC + p.matc_base[t] + pos;
+    const uint32_t stride = p.matc_stride[t];
+    uint32_t sum = 0;
+    for (uint32_t r = 0; r < K; r++) sum += col[(uint64_t)r * stride];
+    p.gcount[p.bbv_base[t] + pos] = sum;
+}
+
 #ifndef DG_EB
 #define DG_EB 16
 #endif
@@ -888,6 +920,8 @@ __global__ __launch_bounds__(64) void k_emit(DgParams p) {
     bool own = true;              // prev was created by this wave (the enter vertex: by the read's first stretch)
     uint32_t i = lo;
     const uint32_t P0 = blockIdx.z << p.emit_shift, P1 = P0 + (1u << p.emit_shift);
+    const bool rvalid = r < K && lane < DG_ERPW;   // the lane has a read of its own (its matC row is its own)
+    bool pfx_entry = false;
     if (!done) {
         if (bbpos >= P1) done = true;                       // the read starts in a later stretch
         else if (bbpos < P0) {
@@ -904,13 +938,27 @@ __global__ __launch_bounds__(64) void k_emit(DgParams p) {
                     if (qb == DG_GAP) { d++; continue; }
                     if (tb == DG_GAP) {                     // last vertex of the insertion run of position P0 - d
                         prev_pos = P0 - d;
-                        const uint32_t c1 = r + 1 < K ? Cm[p.matc_stride[t] + prev_pos] : p.gcount[bv + prev_pos];
-                        prev = gbase[prev_pos] + c1 - 1u;
+                        if (p.emit_scan) pfx_entry = true;       // (the prefix over the reads is taken below, by the wave)
+                        else {
+                            const uint32_t c1 = r + 1 < K ? Cm[p.matc_stride[t] + prev_pos] : p.gcount[bv + prev_pos];
+                            prev = gbase[prev_pos] + c1 - 1u;
+                        }
                         prev_bb = false;
                         break;
                     }
                 }
             }
+        }
+    }
+    // p.emit_scan (targets of at most a wave of reads): matC holds the run lengths themselves and the wave takes the
+    // prefix over the reads where it needs it -- here for the lanes that enter the stretch behind an insertion run
+    // (one position after the other; few lanes, few positions), per batch of positions below
+    if (p.emit_scan) {
+        for (unsigned long long m = __ballot(pfx_entry); m; m = __ballot(pfx_entry)) {
+            const uint32_t pp = (uint32_t)__builtin_amdgcn_readlane((int)prev_pos, __ffsll((long long)m) - 1);
+            const uint32_t x = rvalid ? Cm[pp] : 0u;
+            const uint32_t e = dg_wave_excl(x, lane);
+            if (pfx_entry && prev_pos == pp) { prev = gbase[pp] + e + x - 1u; pfx_entry = false; }
         }
     }
     uint32_t c_base = 0x80000000u;                // first column staged in colw[] (nothing yet)
@@ -980,6 +1028,13 @@ __global__ __launch_bounds__(64) void k_emit(DgParams p) {
             for (int k = 0; k < DG_EB / 4; k++) {
                 const uint4 v = cp[k];
                 cmv[4 * k] = v.x; cmv[4 * k + 1] = v.y; cmv[4 * k + 2] = v.z; cmv[4 * k + 3] = v.w;
+            }
+        }
+        if (p.emit_scan) {
+#pragma unroll
+            for (int j = 0; j < DG_EB; j++) {
+                const uint32_t x = rvalid ? cmv[j] : 0u;
+                cmv[j] = __ballot(x != 0u) ? dg_wave_excl(x, lane) : 0u;
             }
         }
         if (!done && i < hi && (i - c_base) + 24u > DG_ECOLS) DG_STAGE(i);
@@ -1083,23 +1138,40 @@ __global__ __launch_bounds__(64) void k_emit(DgParams p) {
     }
     // the read goes on beyond the stretch: the departure of the last vertex created here needs
     // the next vertex of the path (the next stretch's wave writes that vertex's arrival side)
-    if (!done && own) {
+    {
+        const bool ahead = !done && own;
         uint32_t q = bbpos, nxt = 0;
-        bool found = false;
-        while (i < hi) {
-            const uint16_t c = buf[i];
-            const uint8_t qb = DG_Q(c), tb = DG_T(c);
-            if (qb == tb) { nxt = bid[q]; found = true; break; }
-            if (qb == DG_GAP) { q++; i++; continue; }
-            if (tb == DG_GAP) { nxt = gbase[q] + Cm[q]; found = true; break; }
-            i++;
+        bool found = false, pfx_next = false;
+        if (ahead) {
+            while (i < hi) {
+                const uint16_t c = buf[i];
+                const uint8_t qb = DG_Q(c), tb = DG_T(c);
+                if (qb == tb) { nxt = bid[q]; found = true; break; }
+                if (qb == DG_GAP) { q++; i++; continue; }
+                if (tb == DG_GAP) {
+                    if (p.emit_scan) pfx_next = true; else nxt = gbase[q] + Cm[q];
+                    found = true; break;
+                }
+                i++;
+            }
         }
-        if (!found) {                                     // nothing but deletions to the end (:106)
-            nxt = bid[exitpos];
-            Am[(uint64_t)exitpos * K + r] = prev + 1u;
+        if (p.emit_scan) {
+            // (the first vertex of the read's insertion run at position q: the prefix over the reads in front, by the wave)
+            for (unsigned long long m = __ballot(pfx_next); m; m = __ballot(pfx_next)) {
+                const uint32_t pp = (uint32_t)__builtin_amdgcn_readlane((int)q, __ffsll((long long)m) - 1);
+                const uint32_t x = rvalid ? Cm[pp] : 0u;
+                const uint32_t e = dg_wave_excl(x, lane);
+                if (pfx_next && q == pp) { nxt = gbase[pp] + e; pfx_next = false; }
+            }
         }
-        const uint32_t pos0 = 0xFFFFFFFFu;                // no row of this departure is staged any more
-        DG_DEPART(nxt);
+        if (ahead) {
+            if (!found) {                                     // nothing but deletions to the end (:106)
+                nxt = bid[exitpos];
+                Am[(uint64_t)exitpos * K + r] = prev + 1u;
+            }
+            const uint32_t pos0 = 0xFFFFFFFFu;                // no row of this departure is staged any more
+            DG_DEPART(nxt);
+        }
     }
 #undef DG_EPW
 #undef DG_ECELL
