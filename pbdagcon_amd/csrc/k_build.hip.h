@@ -778,7 +778,7 @@ __global__ __launch_bounds__(1024) void k_gscan(DgParams p) {
 // the departure side of every vertex it created (`own`): for the last one it looks ahead,
 // past the stretch's end, for the vertex the read goes to next.
 //
-// The lanes walk the backbone in lock step, 16 positions per batch.  In a batch a
+// The lanes walk the backbone in lock step, DG_EB positions per batch.  In a batch a
 // lane first emits the insertion columns in front of a position and then its match
 // / deletion column; the arrival cell of the position stays in a register and the
 // departure cells in LDS, and the whole batch is written at its end as 16 + 16
@@ -874,7 +874,8 @@ __global__ __launch_bounds__(256) void k_gsum(DgParams p) {
 }
 
 #ifndef DG_EB
-#define DG_EB 16
+#define DG_EB 8             // positions per batch (round 3, with the fold inside: 4 / 8 / 16 -> 73 / 86 / 122 VGPRs, 6 / 5 / 4 waves per
+                            // SIMD, build 11.47 / 11.21 / 11.43 ms at configs[1])
 #endif
 #ifndef DG_ERPW
 #define DG_ERPW 64          // reads per wave (16 or 32 were tried: no faster)
