@@ -169,19 +169,22 @@ def rehearse(args, rank, world):
 
 
 # ------------------------------------------------------------------ streaming: configs[3]
-def raw_fasta(ids, raw):
-    """FASTA records (main.cpp:141-143) straight from a dagcon_results struct."""
+def raw_snapshot(raw):
+    """What a dagcon_results struct points at, copied out (the context's host buffers are its own until its next fetch)."""
     import ctypes as C
     import numpy as np
-    blob = C.string_at(raw.seq_blob, raw.seq_bytes) if raw.seq_bytes else b""
     T, S = raw.n_targets, raw.n_segments
+    blob = C.string_at(raw.seq_blob, raw.seq_bytes) if raw.seq_bytes else b""
     if not S:
-        return b""
-    begin = np.ctypeslib.as_array(raw.seg_begin, (T + 1,)).tolist()
-    r0 = np.ctypeslib.as_array(raw.range0, (S,)).tolist()
-    r1 = np.ctypeslib.as_array(raw.range1, (S,)).tolist()
-    off = np.ctypeslib.as_array(raw.seq_off, (S,)).tolist()
-    ln = np.ctypeslib.as_array(raw.seq_len, (S,)).tolist()
+        return T, [0] * (T + 1), [], [], [], [], blob
+    return (T, np.ctypeslib.as_array(raw.seg_begin, (T + 1,)).tolist(), np.ctypeslib.as_array(raw.range0, (S,)).tolist(),
+            np.ctypeslib.as_array(raw.range1, (S,)).tolist(), np.ctypeslib.as_array(raw.seq_off, (S,)).tolist(),
+            np.ctypeslib.as_array(raw.seq_len, (S,)).tolist(), blob)
+
+
+def snapshot_fasta(ids, snap):
+    """FASTA records (main.cpp:141-143) of a snapshot."""
+    T, begin, r0, r1, off, ln, blob = snap
     out = []
     for t in range(T):
         for s in range(begin[t], begin[t + 1]):
@@ -189,6 +192,11 @@ def raw_fasta(ids, raw):
             out.append(blob[off[s]:off[s] + ln[s]])
             out.append(b"\n")
     return b"".join(out)
+
+
+def snapshot_results(snap):
+    T, begin, r0, r1, off, ln, blob = snap
+    return [[(r0[s], r1[s], blob[off[s]:off[s] + ln[s]]) for s in range(begin[t], begin[t + 1])] for t in range(T)]
 
 
 def stream_core(ctxs, batches, B, on_result=None, sync=None):
@@ -350,20 +358,39 @@ def stream_worker(args, rank, world, local_rank, quiet=False):
 
     all_ids = [target_ids(f, n, args.tlen) for f, n in mine]
 
+    # the thread that fetches only copies a batch's results out and hands the context back; records are formatted,
+    # digested and (every --gather-every batches) gathered by a writer thread, in order -- the reference's Writer
+    # (main.cpp:164-175) beside its consensus workers
+    import queue
+    import threading
+    wq = queue.Queue()
+    werr = []
+
+    def writer():
+        try:
+            while True:
+                item = wq.get()
+                if item is None:
+                    return
+                i, snap = item
+                f, n = mine[i]
+                fa = snapshot_fasta(all_ids[i], snap)
+                parts.append(fa)
+                if n == distinct[i % nd].n_targets:
+                    d = seqs_only(fa)
+                    if i < nd:
+                        seq_digest[i] = d
+                        keep_first[i] = snapshot_results(snap) if args.stream_verify else None
+                    elif seq_digest.get(i % nd) != d:
+                        reuse_ok[0] = False
+                state["done"] += 1
+                if state["done"] % args.gather_every == 0:
+                    gather_round()
+        except Exception as e:
+            werr.append(e)
+
     def on_result(i, raw):
-        f, n = mine[i]
-        fa = raw_fasta(all_ids[i], raw)
-        parts.append(fa)
-        if n == distinct[i % nd].n_targets:
-            d = seqs_only(fa)
-            if i < nd:
-                seq_digest[i] = d
-                keep_first[i] = ctxs[0].results_to_py(raw) if args.stream_verify else None
-            elif seq_digest.get(i % nd) != d:
-                reuse_ok[0] = False
-        state["done"] += 1
-        if state["done"] % args.gather_every == 0:
-            gather_round()
+        wq.put((i, raw_snapshot(raw)))
 
     def fence():
         if dist is not None:
@@ -381,7 +408,15 @@ def stream_worker(args, rank, world, local_rank, quiet=False):
             if state["done"] % args.gather_every == 0:
                 gather_round()
     elif B:
-        _, bases, dev_ms, _ = stream_core(ctxs, batch_of, B, on_result)
+        wt = threading.Thread(target=writer)
+        wt.start()
+        try:
+            _, bases, dev_ms, _ = stream_core(ctxs, batch_of, B, on_result)
+        finally:
+            wq.put(None)
+            wt.join()
+        if werr:
+            raise werr[0]
     while state["round"] < n_rounds:                 # the tail, and the rounds a shorter shard sits out with nothing to send
         gather_round()
     fence()
