@@ -101,6 +101,7 @@ struct Ctx {
     int bp_fused = 1;                              // partial-span bestPath: one (A, B) sweep + vertex-parallel kernels (DAGCON_BP_FUSED=0: three sweeps)
     uint32_t align_dropped = 0;                    // records of the last dagcon_align / dagcon_consensus_pre the band could not align
     int emit_scan = 1;                             // k_emit takes the prefix over the reads itself (DAGCON_EMIT_SCAN=0: k_groups, as for deeper targets)
+    int nf2 = 1;                                   // k_norm_finish2 (a wave per chunk) instead of k_norm_finish (DAGCON_NF2=0)
     int fold = 1;                                  // duplicate insertion chains folded by k_emit (DAGCON_FOLD=0: never)
     int merge_q = 1, use_q = 0;                    // k_merge_q: four segments per wave (DAGCON_MERGE_Q=0: never); this batch
     uint32_t max_k = 0, max_tlen = 0;
@@ -331,7 +332,8 @@ void launch_normalize(Ctx *c, const DgParams &p) {
     hipLaunchKernelGGL((k_norm_chunk<DG_NW, 64, false>), dim3((c->n_chunks + 63) / 64), dim3(64), 0, s, p);
     hipLaunchKernelGGL((k_norm_chunk<DG_NW_BIG, 32, true>), dim3((c->n_chunks + 31) / 32), dim3(32), 0, s, p);
     hipLaunchKernelGGL(k_norm_scan, dim3((c->A + 63) / 64), dim3(64), 0, s, p);
-    hipLaunchKernelGGL(k_norm_finish, dim3((c->n_chunks + 63) / 64), dim3(64), 0, s, p);
+    if (c->nf2) hipLaunchKernelGGL(k_norm_finish2, dim3((c->n_chunks + 3) / 4), dim3(256), 0, s, p);    // a wave per chunk
+    else hipLaunchKernelGGL(k_norm_finish, dim3((c->n_chunks + 63) / 64), dim3(64), 0, s, p);          // a lane per chunk (DAGCON_NF2=0)
     hipLaunchKernelGGL(k_normalize_slow, dim3((c->A + 63) / 64), dim3(64), 0, s, p);
 }
 
@@ -473,6 +475,7 @@ int dagcon_create(const dagcon_opts *opts, dagcon_ctx **out) {
         if (v >= 1 && v <= 64) c->seg_env = (uint32_t)v;
     }
     if (const char *e = getenv("DAGCON_FOLD")) c->fold = atoi(e) != 0;
+    if (const char *e = getenv("DAGCON_NF2")) c->nf2 = atoi(e) != 0;
     if (const char *e = getenv("DAGCON_EMIT_SCAN")) c->emit_scan = atoi(e) != 0;
     if (const char *e = getenv("DAGCON_BP_FUSED")) c->bp_fused = atoi(e) != 0;
 #ifdef DG_EXPERIMENTS

@@ -503,6 +503,150 @@ __global__ __launch_bounds__(64) void k_norm_finish(DgParams p) {
     if (graph && any && !conf) dg_fail_aln(p, a, DG_E_NONCONF);
 }
 
+// exclusive prefix sum over the lanes of a wave: four DPP row shifts inside the rows of 16 lanes, two row broadcasts
+// across them (lanes without a source add 0); no LDS
+__device__ __forceinline__ uint32_t dg_wave_excl(const uint32_t v, const int lane) {
+    int incl = (int)v;
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xf, 0xf, false);     // row_shr:1
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xf, 0xf, false);     // row_shr:2
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xf, 0xf, false);     // row_shr:4
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xf, 0xf, false);     // row_shr:8
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x142, 0xa, 0xf, false);     // row_bcast:15 into rows 1 and 3
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x143, 0xc, 0xf, false);     // row_bcast:31 into rows 2 and 3
+    (void)lane;
+    return (uint32_t)incl - v;
+}
+
+// ---------------------------------------------------------------------------
+// k_norm_finish2: what k_norm_finish does, a WAVE per chunk (round 3).  With a lane per chunk every lane streams lines
+// of its own, a whole grid apart: 16-byte accesses that share nothing, half a million chunks in flight, their partly
+// written lines (matC cells above all: 4 bytes here, 4 bytes there along a row) pushed out of the L2s before the next
+// store to them arrives -- 4.7 GB of traffic for a 0.9 GB copy.  Here the 64 lanes take consecutive 16-byte pieces of ONE
+// chunk (8 columns each, 512 per pass): the copy is two coalesced loads and a funnelled, aligned, coalesced store; how
+// many target bases lie in front of a lane's columns is a prefix sum over the lanes, how long the insertion run in
+// front of them is a segmented one (reset at every lane that holds a match / deletion column); then every lane walks its
+// own 8 columns as k_norm_finish walks them all.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_norm_finish2(DgParams p) {
+    const uint32_t g = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (g >= p.n_chunks) return;
+    if (dg_failed(p)) return;
+    const int lane = threadIdx.x & 63;
+    const uint32_t a = p.ch_aln[g];
+    if (dg_askip(p, a)) return;
+    const uint32_t o = p.ch_out[g];
+    if (o == DG_CH_NONE) return;
+    const uint32_t hi = p.n_hi[a];
+    if (hi == DG_REDO) return;
+    const uint32_t lo = p.n_lo[a], start = p.n_start[a], lb = p.n_lb[a];
+    const uint32_t w = p.ch_w[g], adv0 = p.ch_adv[g];
+    const uint16_t *src = p.norm_tmp + p.ch_src[g];                  // 16-byte aligned
+    const uint4 *src4 = reinterpret_cast<const uint4 *>(src);
+    uint16_t *dst = p.norm + p.norm_off[a] + o;                       // norm_off is a multiple of 8 columns
+    const bool graph = !(p.flags & DG_F_A1_ONLY);
+    uint32_t t_idx = 0;
+    uint32_t *Cm = nullptr;
+    if (graph) {
+        t_idx = p.aln_tgt[a];
+        if (p.tactive[t_idx]) Cm = p.matC + p.matc_base[t_idx] + (uint64_t)(a - p.aln_begin[t_idx]) * p.matc_stride[t_idx];   // the read's row
+    }
+    const uint32_t tlen = graph ? p.tlen[t_idx] : 0xFFFFFFFFu;
+    uint32_t *ck = p.ckpt + p.ck_base[a];
+    const uint32_t ck_mask = (1u << p.emit_shift) - 1u;
+    const uint32_t adv_init = adv0 > lb ? adv0 - lb : 0u;            // target bases between the trimmed start and this chunk
+    const uint32_t f0 = lo > o ? lo - o : 0u;
+    const uint32_t f1 = hi > o ? (hi - o < w ? hi - o : w) : 0u;
+    const bool any = f1 > f0;
+    const uint32_t fspan = any ? f1 - f0 : 0u;
+    // conformity as k_norm_finish keeps it: true while start - 1 + (target bases so far) <= tlen
+#define DG_NF2_CONF(A) (start >= 1u && ((A) == 0u || (uint64_t)start - 1u + (A) <= (uint64_t)tlen))
+    const uint32_t h0 = (8u - (o & 7u)) & 7u;
+    const uint32_t h = h0 < w ? h0 : w;
+    const uint32_t nb = (w - h) / 8u, nvec = (w + 7u) / 8u;
+    // head and tail of the copy: single columns
+    if ((uint32_t)lane < h) dst[lane] = src[lane];
+    { const uint32_t x = h + 8u * nb + (uint32_t)lane; if (lane < 8 && x < w) dst[x] = src[x]; }
+    uint4 *dst4 = reinterpret_cast<uint4 *>(dst + h);
+    uint32_t adv_tile = adv_init, run_tile = 0, n_ins = 0, n_del = 0;
+    for (uint32_t v0 = 0; v0 < nvec; v0 += 64u) {
+        const uint32_t v = v0 + (uint32_t)lane;
+        uint4 cur = make_uint4(0, 0, 0, 0), nxt = make_uint4(0, 0, 0, 0);
+        if (v < nvec) cur = src4[v];
+        if (v + 1 < nvec) nxt = src4[v + 1];
+        if (v < nb) dst4[v] = dg_funnel_cols(cur, nxt, h);
+        if (!any || 8u * v0 >= f1) continue;                          // (uniform) nothing of the window from here on
+        // ---- the lane's 8 columns: classes, inside the trimmed window only ----
+        const uint32_t w4[4] = {cur.x, cur.y, cur.z, cur.w};
+        uint32_t advm = 0, insm = 0, delm = 0;                        // bit k: column k advances the cursor / is an insertion / a deletion
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const uint16_t c = (uint16_t)((k & 1) ? w4[k >> 1] >> 16 : w4[k >> 1] & 0xffffu);
+            const bool inw = v < nvec && 8u * v + (uint32_t)k - f0 < fspan;
+            const uint8_t qb = DG_Q(c), tb = DG_T(c);
+            const bool adv = inw && (qb == tb || qb == DG_GAP);
+            advm |= adv ? 1u << k : 0u;
+            delm |= (adv && qb != tb) ? 1u << k : 0u;
+            insm |= (inw && !adv && tb == DG_GAP) ? 1u << k : 0u;
+        }
+        const uint32_t nadv = (uint32_t)__popc(advm), nI = (uint32_t)__popc(insm);
+        n_ins += nI; n_del += (uint32_t)__popc(delm);
+        // target bases in front of the lane's columns
+        const uint32_t adv_lane = adv_tile + dg_wave_excl(nadv, lane);
+        // insertion columns since the last advancing column in front of the lane's columns: a scan of (reset, value)
+        // pairs, (f1, v1) then (f2, v2) = (f1 | f2, f2 ? v2 : v1 + v2)
+        uint32_t sf = advm ? 1u : 0u;
+        uint32_t sv = advm ? (uint32_t)__popc(insm & ~((2u << (31 - __clz((int)advm))) - 1u)) : nI;      // behind its last advancing column
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t pf = (uint32_t)__shfl_up((int)sf, d), pv = (uint32_t)__shfl_up((int)sv, d);
+            if (lane >= d) { sv = sf ? sv : pv + sv; sf |= pf; }
+        }
+        // exclusive: what the lane in front ends with (the pass's first lane: what the pass before ended with)
+        uint32_t ef = (uint32_t)__shfl_up((int)sf, 1), ev = (uint32_t)__shfl_up((int)sv, 1);
+        if (lane == 0) { ef = 0; ev = 0; }
+        uint32_t run = ef ? ev : ev + run_tile;
+        const uint32_t lf = (uint32_t)__builtin_amdgcn_readlane((int)sf, 63), lv = (uint32_t)__builtin_amdgcn_readlane((int)sv, 63);
+        run_tile = lf ? lv : lv + run_tile;
+        adv_tile += (uint32_t)__builtin_amdgcn_readlane((int)(adv_lane - adv_tile + nadv), 63);
+        // ---- the lane walks its columns (k_norm_finish's loop body) ----
+        uint32_t adv = adv_lane;
+        if (Cm && (advm | insm)) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                if ((advm >> k) & 1u) {
+                    const bool conf = DG_NF2_CONF(adv);
+                    const uint32_t x = 8u * v + (uint32_t)k;
+                    // (the first column of a chunk inside the window: the chunk in front records it,
+                    // it may end in the insertion run that belongs to this position)
+                    if (conf && ((start + adv) & ck_mask) == 0 && start + adv <= tlen + 1 && !(x == 0 && o > lo))
+                        ck[(start + adv) >> p.emit_shift] = o + x - run;
+                    if (run && conf && start + adv <= tlen + 1) Cm[start + adv] = run;
+                    run = 0;
+                    adv++;
+                } else if ((insm >> k) & 1u) run++;
+            }
+        }
+    }
+    // the column after the chunk is a match (the next chunk's first) or the end of the window;
+    // a trailing insertion run of the read belongs to the position after its last one
+    {
+        const uint32_t adv = adv_tile, run = run_tile;
+        const bool conf = DG_NF2_CONF(adv);
+        if (lane == 0) {
+            if (any && Cm && conf && ((start + adv) & ck_mask) == 0 && start + adv <= tlen + 1 && (o + f1 < hi || run))
+                ck[(start + adv) >> p.emit_shift] = o + f1 - run;
+            if (run && Cm && conf && start + adv <= tlen + 1) Cm[start + adv] = run;
+            if (graph && any && !conf) dg_fail_aln(p, a, DG_E_NONCONF);
+        }
+    }
+    // totals of the chunk
+    {
+        const uint32_t ti = dg_wave_excl(n_ins, lane) + n_ins, td = dg_wave_excl(n_del, lane) + n_del;
+        if (lane == 63) { if (ti) atomicAdd(&p.n_ins[a], ti); if (td) atomicAdd(&p.n_del[a], td); }
+    }
+#undef DG_NF2_CONF
+}
+
 // The same algorithm with the whole expanded alignment in HBM: raw mode and
 // alignments whose look-ahead outgrew the LDS window.
 __global__ __launch_bounds__(64) void k_normalize_slow(DgParams p) {
@@ -839,20 +983,6 @@ __device__ __forceinline__ bool dg_emit_fold(unsigned long long em, const uint32
         }
     }
     return victim;
-}
-
-// exclusive prefix sum over the lanes of a wave: four DPP row shifts inside the rows of 16 lanes, two row broadcasts
-// across them (lanes without a source add 0); no LDS
-__device__ __forceinline__ uint32_t dg_wave_excl(const uint32_t v, const int lane) {
-    int incl = (int)v;
-    incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xf, 0xf, false);     // row_shr:1
-    incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xf, 0xf, false);     // row_shr:2
-    incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xf, 0xf, false);     // row_shr:4
-    incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xf, 0xf, false);     // row_shr:8
-    incl += __builtin_amdgcn_update_dpp(0, incl, 0x142, 0xa, 0xf, false);     // row_bcast:15 into rows 1 and 3
-    incl += __builtin_amdgcn_update_dpp(0, incl, 0x143, 0xc, 0xf, false);     // row_bcast:31 into rows 2 and 3
-    (void)lane;
-    return (uint32_t)incl - v;
 }
 
 // ---------------------------------------------------------------------------
