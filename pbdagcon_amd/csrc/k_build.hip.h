@@ -522,11 +522,14 @@ __device__ __forceinline__ uint32_t dg_wave_excl(const uint32_t v, const int lan
 // of its own, a whole grid apart: 16-byte accesses that share nothing, half a million chunks in flight, their partly
 // written lines (matC cells above all: 4 bytes here, 4 bytes there along a row) pushed out of the L2s before the next
 // store to them arrives -- 4.7 GB of traffic for a 0.9 GB copy.  Here the 64 lanes take consecutive 16-byte pieces of ONE
-// chunk (8 columns each, 512 per pass): the copy is two coalesced loads and a funnelled, aligned, coalesced store; how
+// chunk (8 columns each, 512 per pass): the copy is coalesced loads and funnelled, aligned, coalesced stores; how
 // many target bases lie in front of a lane's columns is a prefix sum over the lanes, how long the insertion run in
 // front of them is a segmented one (reset at every lane that holds a match / deletion column); then every lane walks its
 // own 8 columns as k_norm_finish walks them all.
 // ---------------------------------------------------------------------------
+#ifndef DG_NF2_V
+#define DG_NF2_V 1            // (2: one pass per chunk instead of two, and no faster: 6.0 against 5.9 ms of normalize)
+#endif
 __global__ __launch_bounds__(256) void k_norm_finish2(DgParams p) {
     const uint32_t g = blockIdx.x * 4u + (threadIdx.x >> 6);
     if (g >= p.n_chunks) return;
@@ -568,20 +571,24 @@ __global__ __launch_bounds__(256) void k_norm_finish2(DgParams p) {
     { const uint32_t x = h + 8u * nb + (uint32_t)lane; if (lane < 8 && x < w) dst[x] = src[x]; }
     uint4 *dst4 = reinterpret_cast<uint4 *>(dst + h);
     uint32_t adv_tile = adv_init, run_tile = 0, n_ins = 0, n_del = 0;
-    for (uint32_t v0 = 0; v0 < nvec; v0 += 64u) {
-        const uint32_t v = v0 + (uint32_t)lane;
-        uint4 cur = make_uint4(0, 0, 0, 0), nxt = make_uint4(0, 0, 0, 0);
-        if (v < nvec) cur = src4[v];
-        if (v + 1 < nvec) nxt = src4[v + 1];
-        if (v < nb) dst4[v] = dg_funnel_cols(cur, nxt, h);
+    // a lane takes DG_NF2_V consecutive 16-byte pieces: a chunk of 512 input columns is ~550 columns here, one pass of 1024
+    constexpr uint32_t NV = DG_NF2_V, NC = 8u * NV;
+    for (uint32_t v0 = 0; v0 < nvec; v0 += 64u * NV) {
+        const uint32_t vl = v0 + NV * (uint32_t)lane;                // the lane's first piece
+        uint4 pc[NV + 1];
+#pragma unroll
+        for (uint32_t j = 0; j <= NV; j++) pc[j] = vl + j < nvec ? src4[vl + j] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (uint32_t j = 0; j < NV; j++) if (vl + j < nb) dst4[vl + j] = dg_funnel_cols(pc[j], pc[j + 1], h);
         if (!any || 8u * v0 >= f1) continue;                          // (uniform) nothing of the window from here on
-        // ---- the lane's 8 columns: classes, inside the trimmed window only ----
-        const uint32_t w4[4] = {cur.x, cur.y, cur.z, cur.w};
+        // ---- the lane's columns: classes, inside the trimmed window only ----
         uint32_t advm = 0, insm = 0, delm = 0;                        // bit k: column k advances the cursor / is an insertion / a deletion
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const uint16_t c = (uint16_t)((k & 1) ? w4[k >> 1] >> 16 : w4[k >> 1] & 0xffffu);
-            const bool inw = v < nvec && 8u * v + (uint32_t)k - f0 < fspan;
+        for (uint32_t k = 0; k < NC; k++) {
+            const uint4 q4 = pc[k >> 3];
+            const uint32_t wd = ((k >> 1) & 3u) == 0 ? q4.x : ((k >> 1) & 3u) == 1 ? q4.y : ((k >> 1) & 3u) == 2 ? q4.z : q4.w;
+            const uint16_t c = (uint16_t)((k & 1u) ? wd >> 16 : wd & 0xffffu);
+            const bool inw = 8u * vl + k < 8u * nvec && 8u * vl + k - f0 < fspan;
             const uint8_t qb = DG_Q(c), tb = DG_T(c);
             const bool adv = inw && (qb == tb || qb == DG_GAP);
             advm |= adv ? 1u << k : 0u;
@@ -612,10 +619,10 @@ __global__ __launch_bounds__(256) void k_norm_finish2(DgParams p) {
         uint32_t adv = adv_lane;
         if (Cm && (advm | insm)) {
 #pragma unroll
-            for (int k = 0; k < 8; k++) {
+            for (uint32_t k = 0; k < NC; k++) {
                 if ((advm >> k) & 1u) {
                     const bool conf = DG_NF2_CONF(adv);
-                    const uint32_t x = 8u * v + (uint32_t)k;
+                    const uint32_t x = 8u * vl + k;
                     // (the first column of a chunk inside the window: the chunk in front records it,
                     // it may end in the insertion run that belongs to this position)
                     if (conf && ((start + adv) & ck_mask) == 0 && start + adv <= tlen + 1 && !(x == 0 && o > lo))
