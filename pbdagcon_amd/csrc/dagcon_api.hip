@@ -102,6 +102,7 @@ struct Ctx {
     uint32_t align_dropped = 0;                    // records of the last dagcon_align / dagcon_consensus_pre the band could not align
     int emit_scan = 1;                             // k_emit takes the prefix over the reads itself (DAGCON_EMIT_SCAN=0: k_groups, as for deeper targets)
     int nf2 = 1;                                   // k_norm_finish2 (a wave per chunk) instead of k_norm_finish (DAGCON_NF2=0)
+    int poison = 0;                                // DAGCON_POISON (tests): arenas nobody clears are filled with 0xEE bytes before every run
     int fold = 1;                                  // duplicate insertion chains folded by k_emit (DAGCON_FOLD=0: never)
     int merge_q = 1, use_q = 0;                    // k_merge_q: four segments per wave (DAGCON_MERGE_Q=0: never); this batch
     uint32_t max_k = 0, max_tlen = 0;
@@ -348,6 +349,14 @@ int launch_all(Ctx *c) {
     HIPCHK(c, hipMemsetAsync(c->d_cns_len.p, 0, (size_t)c->T * 4, s));
     HIPCHK(c, hipMemsetAsync(c->d_n_seg.p, 0, (size_t)c->T * 4, s));
     if (c->matc_cells) HIPCHK(c, hipMemsetAsync(c->d_matC.p, 0, c->matc_cells * 4, s));
+    if (c->poison) {
+        // what no kernel is supposed to read before it has been written in THIS run: a process that re-uses its
+        // arenas (another context's freed memory, the batch before) finds old cells there, not the zeros of a fresh one
+        if ((c->poison & 1) && c->d_matA.p) { HIPCHK(c, hipMemsetAsync(c->d_matA.p, 0xEE, c->d_matA.cap, s)); HIPCHK(c, hipMemsetAsync(c->d_matD.p, 0xEE, c->d_matD.cap, s)); }
+        if ((c->poison & 2) && c->d_nodes.p) { HIPCHK(c, hipMemsetAsync(c->d_nodes.p, 0xEE, c->d_nodes.cap, s)); HIPCHK(c, hipMemsetAsync(c->d_pool.p, 0xEE, c->d_pool.cap, s)); }
+        if ((c->poison & 4) && c->d_score_b.p) HIPCHK(c, hipMemsetAsync(c->d_score_b.p, 0xEE, c->d_score_b.cap, s));
+        if ((c->poison & 4) && c->d_norm.p) HIPCHK(c, hipMemsetAsync(c->d_norm.p, 0xEE, c->d_norm.cap, s));
+    }
     HIPCHK(c, hipEventRecord(c->ev[0], s));
     launch_normalize(c, p);
     HIPCHK(c, hipEventRecord(c->ev[1], s));
@@ -475,6 +484,7 @@ int dagcon_create(const dagcon_opts *opts, dagcon_ctx **out) {
         if (v >= 1 && v <= 64) c->seg_env = (uint32_t)v;
     }
     if (const char *e = getenv("DAGCON_FOLD")) c->fold = atoi(e) != 0;
+    if (const char *e = getenv("DAGCON_POISON")) c->poison = atoi(e);
     if (const char *e = getenv("DAGCON_NF2")) c->nf2 = atoi(e) != 0;
     if (const char *e = getenv("DAGCON_EMIT_SCAN")) c->emit_scan = atoi(e) != 0;
     if (const char *e = getenv("DAGCON_BP_FUSED")) c->bp_fused = atoi(e) != 0;

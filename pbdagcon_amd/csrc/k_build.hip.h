@@ -1251,7 +1251,10 @@ __global__ __launch_bounds__(64) void k_emit(DgParams p) {
                         // chain (k_lists counts the out-edge with them), a victim's is empty
                         const uint32_t dv = vic ? 0u : (f_first + 1u) | ((fn - 1u) << 25);
                         if (f_apos >= pos0) s_D[(f_apos - pos0) * 64 + lane] = dv;
-                        else DG_ECELL(Dm, f_apos) = dv;
+                        // (enter's row, position 0, leaves a batch only where a cell is not 0 -- its cells belong to
+                        // whichever stretch a read starts in -- so a victim's empty cell there is stored here; nobody
+                        // clears the matrix, and a stale cell would be a vertex that does not exist)
+                        if (f_apos < pos0 || f_apos == 0u) DG_ECELL(Dm, f_apos) = dv;
                         if (vic) acell[j] = (acell[j] & 0xFE000000u) | DG_CELL_DUP;
                     }
                 }
