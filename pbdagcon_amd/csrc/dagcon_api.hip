@@ -20,6 +20,7 @@
 #include "k_build.hip.h"
 #include "k_merge.hip.h"
 #ifdef DG_EXPERIMENTS
+#include "experiments/k_align2.hip.h"        // the following band with two pairs per wave: exact, 86 ms against 60
 #include "experiments/k_emit2.hip.h"         // addAln with a thread per column: exact, and 15.6 ms of build against 12.4
 #include "experiments/k_merge_tile.hip.h"     // dropped experiments: `make experiments` only, never in the shipped library
 #endif
@@ -103,6 +104,7 @@ struct Ctx {
     int emit_scan = 1;                             // k_emit takes the prefix over the reads itself (DAGCON_EMIT_SCAN=0: k_groups, as for deeper targets)
     int nf2 = 1;                                   // k_norm_finish2 (a wave per chunk) instead of k_norm_finish (DAGCON_NF2=0)
     int poison = 0;                                // DAGCON_POISON (tests): arenas nobody clears are filled with 0xEE bytes before every run
+    int align2 = 0;                                // (make experiments) k_align_adapt2: two pairs per wave, DAGCON_ALIGN2=1
     int fold = 1;                                  // duplicate insertion chains folded by k_emit (DAGCON_FOLD=0: never)
     int merge_q = 1, use_q = 0;                    // k_merge_q: four segments per wave (DAGCON_MERGE_Q=0: never); this batch
     uint32_t max_k = 0, max_tlen = 0;
@@ -484,6 +486,7 @@ int dagcon_create(const dagcon_opts *opts, dagcon_ctx **out) {
         if (v >= 1 && v <= 64) c->seg_env = (uint32_t)v;
     }
     if (const char *e = getenv("DAGCON_FOLD")) c->fold = atoi(e) != 0;
+    if (const char *e = getenv("DAGCON_ALIGN2")) c->align2 = atoi(e) != 0;
     if (const char *e = getenv("DAGCON_POISON")) c->poison = atoi(e);
     if (const char *e = getenv("DAGCON_NF2")) c->nf2 = atoi(e) != 0;
     if (const char *e = getenv("DAGCON_EMIT_SCAN")) c->emit_scan = atoi(e) != 0;
@@ -1110,6 +1113,10 @@ static int align_device(Ctx *c, uint32_t n, const uint64_t *q_off, const uint32_
             HIPCHK(c, hipMemcpyAsync(ddo.p, dir_off.data(), (size_t)n * 8, hipMemcpyHostToDevice, s));
             HIPCHK(c, hipMemcpyAsync((uint32_t *)didx.p + first, ad.data() + first, cnt * 4, hipMemcpyHostToDevice, s));
             ap.idx = (const uint32_t *)didx.p + first; ap.n = (uint32_t)cnt; ap.first_pass = 1u;
+#ifdef DG_EXPERIMENTS
+            if (c->align2) hipLaunchKernelGGL(k_align_adapt2, dim3((uint32_t)((cnt + 1) / 2)), dim3(64), 0, s, ap);      // two pairs per wave
+            else
+#endif
             hipLaunchKernelGGL(k_align_adapt, dim3((uint32_t)cnt), dim3(64), 0, s, ap);
             HIPCHK(c, hipGetLastError());
             HIPCHK(c, hipStreamSynchronize(s));
