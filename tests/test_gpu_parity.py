@@ -1173,3 +1173,34 @@ def test_nothing_reads_what_this_run_did_not_write(seed, rnd, monkeypatch):
                     assert got == exp, f"{desc} {kw} shift={shift}: targets {[t for t in range(len(exp)) if got[t] != exp[t]][:8]}"
             finally:
                 ctx.close()
+
+
+@pytest.mark.parametrize("knob", ["DAGCON_FOLD", "DAGCON_EMIT_SCAN", "DAGCON_NF2", "DAGCON_BP_FUSED"])
+def test_round3_paths_and_their_checkers_agree(knob, monkeypatch):
+    """Every round-3 path has the path it replaced behind a switch -- the fold (duplicate chains merged by the sweep
+    instead), the wave's own prefix over the reads (k_groups instead), k_norm_finish2 (a lane per chunk instead), the
+    one-sweep partial-span bestPath (three sweeps instead).  Both sides of each switch against the oracle: full-span and
+    partial-span synthetic pileups, adversarial little ones (leading insertions, tiny alphabets), a deep target (more
+    than a wave of reads: the k_groups path whatever the switch says)."""
+    rng = np.random.default_rng(33)
+    batches = [(synth.make_batch(8, 4000, 36, seed=9100), dict(min_cov=6, min_len=500, trim=50)),
+               (synth.make_batch(8, 0, 28, seed=9200, min_span=0.4, tlens=rng.integers(1500, 9000, 8), with_backbone=True),
+                dict(min_cov=6, min_len=300, trim=10)),
+               (synth.make_batch(2, 3000, 90, seed=9300), dict(min_cov=6, min_len=500, trim=50))]
+    targets = []
+    for i in range(40):
+        tl = int(rng.integers(30, 400))
+        alns, bb = random_target(rng, tl, int(rng.integers(3, 24)), alphabet=[b"AC", b"ACGT", b"A"][i % 3],
+                                 ins=float(rng.uniform(0.05, 0.3)), dele=float(rng.uniform(0.02, 0.2)), full_span=(i % 2 == 0))
+        targets.append((tl, alns, bb))
+    batches.append((batch_from_targets(targets), dict(min_cov=0, min_len=0, trim=0, min_weight=0)))
+    for val in ("0", "1"):
+        monkeypatch.setenv(knob, val)
+        for b, kw in batches:
+            exp = oracle_batch(b, kw["min_cov"], kw["min_len"], kw["trim"], kw.get("min_weight"))
+            ctx = capi.Context(**kw)
+            try:
+                got = ctx.consensus(b)
+            finally:
+                ctx.close()
+            assert got == exp, f"{knob}={val}: targets {[t for t in range(len(exp)) if got[t] != exp[t]][:8]}"
