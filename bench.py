@@ -841,69 +841,84 @@ def worker(args, rank, world, local_rank):
                 "same_segments_as_device": segf == res[:nf],
             }
             line["gpu_over_cpu_faithful"] = value / n_gpus / vf
+        def leg(name, fn):
+            """A leg outside the timed region must never take the line down with it: its key says what went wrong."""
+            try:
+                out = fn()
+                if isinstance(out, dict) and name is None:
+                    line.update(out)
+                elif name is not None:
+                    line[name] = out
+            except Exception as e:      # noqa: BLE001
+                line[name or "legs_error"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+
         if not args.no_legs and n_gpus == 1:
-            # host->device copy inside the clock: dagcon_consensus on the warm context (pageable blobs),
-            # then with the blobs in page-locked memory (dagcon_host_alloc)
-            t1 = time.perf_counter()
-            r2 = ctx.consensus(batch)
-            d1 = time.perf_counter() - t1
-            pinned = ctx.pin_batch(batch)
-            t1 = time.perf_counter()
-            r3 = ctx.consensus(pinned)
-            d2 = time.perf_counter() - t1
-            h2d_bytes = 2 * int(batch.qstr.size)
-            line["h2d_inclusive"] = {
-                "value": bases_rank / d2, "unit": "bases/s", "ms": d2 * 1e3, "ms_pageable": d1 * 1e3,
-                "value_pageable": bases_rank / d1, "h2d_bytes": h2d_bytes,
-                "same_results": r2 == res and r3 == res,
-                "what": "dagcon_consensus (host filter + H2D of the strings + kernels + D2H) on a warm context, one "
-                        "batch, nothing overlapped; `value` with the blobs page-locked by dagcon_host_alloc",
-            }
-            if n_gpus == 1:
+            state = {}
+
+            def leg_h2d():
+                # host->device copy inside the clock: dagcon_consensus on the warm context (pageable blobs),
+                # then with the blobs in page-locked memory (dagcon_host_alloc)
+                t1 = time.perf_counter()
+                r2 = ctx.consensus(batch)
+                d1 = time.perf_counter() - t1
+                pinned = ctx.pin_batch(batch)
+                state["pinned"] = pinned
+                t1 = time.perf_counter()
+                r3 = ctx.consensus(pinned)
+                d2 = time.perf_counter() - t1
+                h2d_bytes = 2 * int(batch.qstr.size)
+                return {
+                    "value": bases_rank / d2, "unit": "bases/s", "ms": d2 * 1e3, "ms_pageable": d1 * 1e3,
+                    "value_pageable": bases_rank / d1, "h2d_bytes": h2d_bytes,
+                    "same_results": r2 == res and r3 == res,
+                    "what": "dagcon_consensus (host filter + H2D of the strings + kernels + D2H) on a warm context, one "
+                            "batch, nothing overlapped; `value` with the blobs page-locked by dagcon_host_alloc",
+                }
+
+            def leg_two():
                 # the same batch again and again through TWO contexts (what the CLI does on long inputs): one batch's
                 # upload and result copy run beside the other's kernels, every upload inside the clock
+                pinned = state.get("pinned") or ctx.pin_batch(batch)
+                h2d_bytes = 2 * int(batch.qstr.size)
                 ctx2 = capi.Context(device=local_rank, **opts)
-                ctx2.upload(pinned); ctx2.run(); ctx2.fetch()
-                nb = 8
-                sdt, sbases, sdev, sfirst = stream_core([ctx, ctx2], [pinned], nb)
-                # ... and with the inputs resident (what `value` times, but with two batches in flight)
-                nr = 8
-                both = [ctx, ctx2]
-                ctx.upload(pinned)
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                inflight = []
-                rbases = 0
-                for i in range(nr):
-                    c2 = both[i & 1]
-                    if len(inflight) == 2:
-                        cf = inflight.pop(0); cf.fetch_raw(); rbases += cf.timings()["consensus_bases"]
-                    c2.run(); inflight.append(c2)
-                for cf in inflight:
-                    cf.fetch_raw(); rbases += cf.timings()["consensus_bases"]
-                torch.cuda.synchronize()
-                rdt = time.perf_counter() - t1
-                line["two_contexts"] = {
-                    "value": rbases / rdt, "unit": "bases/s", "steps": nr, "ms_per_step": rdt / nr * 1e3,
-                    "what": "inputs resident as for `value`, but two contexts in flight on one GPU (own non-blocking stream "
-                            "each): one batch's memory-bound kernels and tails run beside the other's issue-bound ones",
+                try:
+                    ctx2.upload(pinned); ctx2.run(); ctx2.fetch()
+                    nb = 8
+                    sdt, sbases, sdev, sfirst = stream_core([ctx, ctx2], [pinned], nb)
+                    # ... and with the inputs resident (what `value` times, but with two batches in flight)
+                    nr = 8
+                    both = [ctx, ctx2]
+                    ctx.upload(pinned)
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    inflight = []
+                    rbases = 0
+                    for i in range(nr):
+                        c2 = both[i & 1]
+                        if len(inflight) == 2:
+                            cf = inflight.pop(0); cf.fetch_raw(); rbases += cf.timings()["consensus_bases"]
+                        c2.run(); inflight.append(c2)
+                    for cf in inflight:
+                        cf.fetch_raw(); rbases += cf.timings()["consensus_bases"]
+                    torch.cuda.synchronize()
+                    rdt = time.perf_counter() - t1
+                finally:
+                    ctx2.close()
+                return {
+                    "two_contexts": {
+                        "value": rbases / rdt, "unit": "bases/s", "steps": nr, "ms_per_step": rdt / nr * 1e3,
+                        "what": "inputs resident as for `value`, but two contexts in flight on one GPU (own non-blocking stream "
+                                "each): one batch's memory-bound kernels and tails run beside the other's issue-bound ones",
+                    },
+                    "streamed": {
+                        "value": sbases / sdt, "unit": "bases/s", "batches": nb, "ms_per_batch": sdt / nb * 1e3,
+                        "h2d_GBps": h2d_bytes * nb / sdt / 1e9, "same_results": sfirst == res,
+                        "what": "8 batches of this workload through two contexts in flight on one GPU, page-locked blobs, "
+                                "host->device copy of every batch and the result copy inside the clock",
+                    },
                 }
-                ctx2.close()
-                line["streamed"] = {
-                    "value": sbases / sdt, "unit": "bases/s", "batches": nb, "ms_per_batch": sdt / nb * 1e3,
-                    "h2d_GBps": h2d_bytes * nb / sdt / 1e9, "same_results": sfirst == res,
-                    "what": "8 batches of this workload through two contexts in flight on one GPU, page-locked blobs, "
-                            "host->device copy of every batch and the result copy inside the clock",
-                }
-            line["e2e"] = e2e_leg(batch, args.e2e_targets, fasta_bytes(batch.select(range(min(args.e2e_targets, batch.n_targets))),
-                                                                      res[:args.e2e_targets]))
-            if n_gpus == 1 and config1:
-                line["e2e_pre"] = e2e_pre_leg(64, 50000, 60, dict(min_cov=8, min_len=500, trim=50))
-            if n_gpus == 1 and config1:
-                line["e2e_4000"] = e2e_leg(batch, args.e2e_targets, fasta_bytes(batch.select(range(min(args.e2e_targets, batch.n_targets))),
-                                                                                 res[:args.e2e_targets]), repeat=4)
-                line["config5_shape"] = config5_leg(local_rank)
-            if n_gpus == 1:
+
+            def leg_c3():
                 # the N = 1 point of configs[3]: 12 batches of this workload's size streamed through two contexts,
                 # uploads inside the clock; batch 0 is the batch `value` was measured on
                 ctx.close()
@@ -912,7 +927,17 @@ def worker(args, rank, world, local_rank):
                 a3.stream_verify, a3.rehearse = 64, False
                 c3 = stream_worker(a3, 0, 1, local_rank, quiet=True)
                 c3["batch0_identical_to_value_run"] = c3.pop("batch0_sha256") == hashlib.sha256(my_fasta).hexdigest()
-                line["configs3_n1"] = c3
+                return c3
+
+            first_fasta = fasta_bytes(batch.select(range(min(args.e2e_targets, batch.n_targets))), res[:args.e2e_targets])
+            leg("h2d_inclusive", leg_h2d)
+            leg(None, leg_two)
+            leg("e2e", lambda: e2e_leg(batch, args.e2e_targets, first_fasta))
+            if config1:
+                leg("e2e_pre", lambda: e2e_pre_leg(64, 50000, 60, dict(min_cov=8, min_len=500, trim=50)))
+                leg("e2e_4000", lambda: e2e_leg(batch, args.e2e_targets, first_fasta, repeat=4))
+                leg("config5_shape", lambda: config5_leg(local_rank))
+            leg("configs3_n1", leg_c3)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
