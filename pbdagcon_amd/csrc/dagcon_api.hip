@@ -578,7 +578,10 @@ static int upload_impl(dagcon_ctx *ctx, const dagcon_batch *b, const void *dev_q
             c->h_aln_tgt.push_back(t);
             c->sum_len += len;
             c->max_len = std::max(c->max_len, len);
-            n_whole += len >= b->tlen[t];                                  // (a read that spans the target has a column per target base)
+            // (a read that spans the target begins at its first base and has a column per target base; necessary, not
+            // sufficient -- a read that ends early and inserts a lot passes too: the batch is then exact all the same, with
+            // fewer cuts than it could have)
+            n_whole += len >= b->tlen[t] && b->aln_start[a] == 1u;
         }
         const uint64_t k = c->h_aln_len.size() - c->h_aln_begin[t];
         if (k > DAGCON_MAX_COVERAGE)
