@@ -47,7 +47,7 @@ struct DgGraph {
     DgStatus *st;
     uint32_t *tfail;               // this target's word of DgParams::tfail
     uint32_t t;
-    bool err;
+    int err;                       // (an int: in k_merge_q it differs from row to row, and a boolean there is a lane mask with merges at every join)
     // Partial-span pileups (k_cuts2): reads that start or end inside the target put enter -> x and
     // x -> exit edges across the cut vertices, so enter's out-list and exit's in-list are touched by
     // every segment's worker, and so are the out-lists of the few vertices the prologue has visited

@@ -16,12 +16,14 @@
 #include "dagcon_dev.h"
 
 #ifndef DQ_W
-#define DQ_W 16                      // lanes of a row
+#define DQ_W 8                       // lanes of a row (round 3: 8 rows of 8 lanes; 4 x 16 / 2 x 32 -> merge 13.3 / 18.9 ms against 11.2 at configs[1])
 #endif
 #define DQ_ROWS (64 / DQ_W)          // rows (segments) of a wave
 #define DQ_ALL ((uint32_t)((1ull << DQ_W) - 1ull))
 #define DQ_LO ((1u << (DQ_W / 2)) - 1u)   // the lower half of a row: in entries of the one-look path
-#define DQ_RING 128                  // the youngest queue entries of a row, in LDS
+#ifndef DQ_RING
+#define DQ_RING 32                   // the youngest queue entries of a row, in LDS
+#endif
 typedef uint32_t qmask;              // one bit per lane of the row
 
 __device__ __forceinline__ qmask dq_ballot(bool p) { return (qmask)((__ballot(p) >> (threadIdx.x & (64u - DQ_W))) & (unsigned long long)DQ_ALL); }
@@ -321,6 +323,10 @@ __device__ inline bool dq_merge_in_group(DgGraph &g, int n, uint32_t n_in_off, q
 }
 
 #define DQ_IN_STACK 48
+// what a row is doing (dq_merge_segment)
+#define DQ_ST_RUN 0                  // visits that merge nothing, one after the other
+#define DQ_ST_NEED 1                 // its visit has a merge group or a long list: the generic code
+#define DQ_ST_END 2                  // the segment is done (or has failed)
 
 // One segment [c_start, c_end] of target t, swept by the calling ROW (dg_merge_segment, mode DG_MM_WORKER, no
 // shared lists).  c_end = 0x7fffffff: the segment runs to the exit vertex.
@@ -341,62 +347,75 @@ __device__ __forceinline__ void dq_merge_segment(const DgParams &p, const uint32
     uint32_t qh = 0, qt = 1;
     if (lane == 0) { g.queue[0] = c_start; s_ring[0] = c_start; }
     DQ_FENCE();
-    bool failed = false;
     // Two phases per round, so that the rows of a wave spend their time on the same code: (A) every row runs
     // through the visits that merge nothing (one look, the FIFO bookkeeping) until it meets a visit that has a merge
     // group, or a list longer than half a row, to deal with -- rows that have met theirs wait; (B) those visits, by
     // the generic code, all rows at once.
-    bool finished = false;
-    while (!finished && !failed) {
-        int u = -1;
-        bool need = false, skip_in = false, in_only = false;
-        while (qh < qt && !failed) {
+    // (What steers a row lives in a vector register, `st`, and the loop of phase A has no way out but its condition:
+    // a boolean that differs from row to row is a lane mask to the compiler, and every such mask that lives across a
+    // branch costs three scalar instructions at every join behind it -- with five of them and breaks from four levels
+    // deep, 115 of the 265 instructions of a visit that merges nothing were mask bookkeeping.)
+    int st = DQ_ST_RUN;
+    int u = -1;
+    for (;;) {
+        while (st == DQ_ST_RUN && qh < qt) {
             if (qt - qh <= DQ_RING) u = s_ring[qh & (DQ_RING - 1)];
             else u = g.queue[qh];
             qh++;
-            if (u < c_start || u > c_hi) { dq_fail(g, DG_E_INTERNAL, lane); failed = true; break; }      // cannot happen (see k_cuts)
-            skip_in = c_start != 0 && u == c_start;        // the previous segment's worker merges in[u]
-            in_only = u == c_end;                          // ... which is this, for the next segment
-            if (in_only && qh != qt) { dq_fail(g, DG_E_INTERNAL, lane); failed = true; break; }
-            // (k_merge asks for the next vertex's record before this visit's stores go out; here the 8 registers that
-            // takes cost more, in waves per SIMD, than the round trip: 17.3 ms with, 16.1 without at configs[1])
-            const uint4 ul = dg_lo16(&DG_NV(g, u)), uh = dg_hi16(&DG_NV(g, u));
-            const int eff_in = skip_in ? 0 : DG_H_INLEN(ul), eff_out = in_only ? 0 : DG_H_OUTLEN(ul);
-            if (eff_in > DQ_W / 2 || eff_out > DQ_W / 2) { need = true; break; }
-            const bool is_in = lane < DQ_W / 2;
-            const int idx = lane & (DQ_W / 2 - 1);
-            const bool valid = is_in ? idx < eff_in : idx < eff_out;
-            const uint32_t ea = is_in ? DG_H2_INOFF(uh) + (uint32_t)idx : DG_H2_OUTOFF(uh) + 2u * (uint32_t)idx;
-            int nbr = 0;
-            if (valid) nbr = (int)DG_PW(g, ea);
-            uint4 h = make_uint4(0, 0, 0, 0);
-            if (valid) h = dg_lo16(&DG_NV(g, nbr));
-            // in lanes: out_len == 1 (low half of h.x), out lanes: in_len == 1 (high half)
-            const qmask cand = dq_ballot(valid && ((h.x >> (is_in ? 0u : 16u)) & 0xffffu) == 1u);
-            // a merge group = two candidates of one side with the same base
-            bool work = false;
-            if (__popc(cand & DQ_LO) >= 2 || __popc(cand & (DQ_ALL & ~DQ_LO)) >= 2) {
-                const int key = ((cand >> lane) & 1u) ? (DG_H_BASE(h) | (is_in ? 0 : 256)) : -1 - lane;
-                for (qmask m = cand; m && !work; m &= m - 1u) {
-                    const int kf = dq_rl(key, __ffs((int)m) - 1);
-                    work = __popc(dq_ballot(key == kf)) >= 2;
+            const bool in_only = u == c_end;               // the next segment's worker does the rest of that visit
+            if (u < c_start || u > c_hi || (in_only && qh != qt)) {       // cannot happen (see k_cuts)
+                dq_fail(g, DG_E_INTERNAL, lane);
+                st = DQ_ST_END;
+            } else {
+                const bool skip_in = c_start != 0 && u == c_start;        // the previous segment's worker merges in[u]
+                // (k_merge asks for the next vertex's record before this visit's stores go out; here the 8 registers that
+                // takes cost more, in waves per SIMD, than the round trip: 17.3 ms with, 16.1 without at configs[1])
+                const uint4 ul = dg_lo16(&DG_NV(g, u)), uh = dg_hi16(&DG_NV(g, u));
+                const int eff_in = skip_in ? 0 : DG_H_INLEN(ul), eff_out = in_only ? 0 : DG_H_OUTLEN(ul);
+                if (eff_in > DQ_W / 2 || eff_out > DQ_W / 2) st = DQ_ST_NEED;
+                else {
+                    const bool is_in = lane < DQ_W / 2;
+                    const int idx = lane & (DQ_W / 2 - 1);
+                    const bool valid = is_in ? idx < eff_in : idx < eff_out;
+                    const uint32_t ea = is_in ? DG_H2_INOFF(uh) + (uint32_t)idx : DG_H2_OUTOFF(uh) + 2u * (uint32_t)idx;
+                    int nbr = 0;
+                    if (valid) nbr = (int)DG_PW(g, ea);
+                    uint4 h = make_uint4(0, 0, 0, 0);
+                    if (valid) h = dg_lo16(&DG_NV(g, nbr));
+                    // in lanes: out_len == 1 (low half of h.x), out lanes: in_len == 1 (high half)
+                    const qmask cand = dq_ballot(valid && ((h.x >> (is_in ? 0u : 16u)) & 0xffffu) == 1u);
+                    // a merge group = two candidates of one side with the same base
+                    int work = 0;
+                    if (__popc(cand & DQ_LO) >= 2 || __popc(cand & (DQ_ALL & ~DQ_LO)) >= 2) {
+                        const int key = ((cand >> lane) & 1u) ? (DG_H_BASE(h) | (is_in ? 0 : 256)) : -1 - lane;
+                        qmask m = cand;
+                        while (m) {
+                            const int kf = dq_rl(key, __ffs((int)m) - 1);
+                            const qmask same = dq_ballot(key == kf);
+                            if (__popc(same) >= 2) { work = 2; m = 0; }
+                            else m &= ~same;
+                        }
+                    }
+                    if (work) st = DQ_ST_NEED;
+                    else if (in_only) st = DQ_ST_END;      // nothing to merge in front of the cut: segment done
+                    else {
+                        // AlnGraphBoost.cpp:143-158
+                        const bool live = valid && !is_in;
+                        const int pend = DG_H_PEND(h) - 1;
+                        const qmask rm = dq_ballot(live && pend == 0);
+                        if (live) DG_NV(g, nbr).pending = pend;
+                        if (live && pend == 0) {
+                            const uint32_t pos = qt + (uint32_t)__popc(rm & DQ_LT(lane));
+                            if (pos < N) { g.queue[pos] = nbr; s_ring[pos & (DQ_RING - 1)] = nbr; }
+                        }
+                        qt += (uint32_t)__popc(rm);
+                        if (qt > N) { dq_fail(g, DG_E_INTERNAL, lane); st = DQ_ST_END; }
+                    }
                 }
             }
-            if (work) { need = true; break; }
-            if (in_only) { finished = true; break; }       // nothing to merge in front of the cut: segment done
-            // AlnGraphBoost.cpp:143-158
-            const bool live = valid && !is_in;
-            const int pend = DG_H_PEND(h) - 1;
-            const qmask rm = dq_ballot(live && pend == 0);
-            if (live) DG_NV(g, nbr).pending = pend;
-            if (live && pend == 0) {
-                const uint32_t pos = qt + (uint32_t)__popc(rm & DQ_LT(lane));
-                if (pos < N) { g.queue[pos] = nbr; s_ring[pos & (DQ_RING - 1)] = nbr; }
-            }
-            qt += (uint32_t)__popc(rm);
-            if (qt > N) { dq_fail(g, DG_E_INTERNAL, lane); failed = true; }
         }
-        if (!need) break;                                  // the queue ran dry, the cut was reached, or something failed
+        if (st != DQ_ST_NEED) break;                       // the queue ran dry, the cut was reached, or something failed
+        const bool skip_in = c_start != 0 && u == c_start, in_only = u == c_end;
         bool scalar = false;
 
         // ---------------- mergeInNodes(u), recursion on an explicit stack ----------------
@@ -499,7 +518,8 @@ __device__ __forceinline__ void dq_merge_segment(const DgParams &p, const uint32
             });
             qt = (uint32_t)dq_rl((int)nqt, 0);
         }
-        failed = g.err;
+        if (g.err) break;
+        st = DQ_ST_RUN;
     }
 }
 
