@@ -956,12 +956,15 @@ __global__ __launch_bounds__(1024) void k_gscan(DgParams p) {
 // first (id of the chain's first vertex), nins.  Returns true for a lane whose chain is folded into an earlier lane's
 // (its arrival cell then becomes DG_CELL_DUP: the column counts as a match, the read brings no in-edge).
 #define DG_CELL_DUP 0x1FFFFFEu
+#define DG_EDONE 0xFFFFFFFFu      // k_emit: a lane that has nothing (left) to do in its stretch
+#define DG_EF_BB 1u               // k_emit, flags of the previous vertex on the read's path: a backbone vertex
+#define DG_EF_OWN 2u              //         created by this wave
 // key of a chain that closed at position pos: its (at most three) inserted bases, and in the top byte how far back the
 // backbone vertex in front of it lies (1: the usual insertion, 2: the insertion half of a substitution, ...); 0 = no
 // chain to compare.  Chains at one position with equal keys are duplicates.
-__device__ __forceinline__ bool dg_emit_fold(unsigned long long em, const uint32_t key, const uint32_t first, const uint32_t pos,
-                                             DgNode *ndt, uint32_t *pool, uint32_t *n_out, const int lane) {
-    bool victim = false;
+__device__ __forceinline__ uint32_t dg_emit_fold(unsigned long long em, const uint32_t key, const uint32_t first, const uint32_t pos,
+                                                 DgNode *ndt, uint32_t *pool, uint32_t *n_out, const int lane) {
+    uint32_t victim = 0;
     *n_out = 0;
     while (em & (em - 1ull)) {                            // two or more chains left to compare
         const int f = __ffsll((long long)em) - 1;
@@ -981,7 +984,7 @@ __device__ __forceinline__ bool dg_emit_fold(unsigned long long em, const uint32
                 pool[3u * rk + 1u] = n;
             }
         } else {
-            victim = true;
+            victim = 1;
             for (uint32_t k = 0; k < nins; k++) {
                 // out_len = in_len = 0, flags = deleted (AlnGraphBoost.cpp:269-273); the base stays
                 const uint32_t base = (key >> (8u * (nins - 1u - k))) & 0xFFu;
@@ -1033,8 +1036,8 @@ __global__ __launch_bounds__(64) void k_emit(DgParams p) {
     const uint32_t K = (uint32_t)(p.aln_begin[t + 1] - ab);
     const uint32_t r = blockIdx.y * DG_ERPW + lane;
     if (blockIdx.y * DG_ERPW >= K) return;
-    bool done = r >= K || lane >= DG_ERPW;         // idle lanes stay in the wave (shuffles, votes)
-    const uint32_t a = (uint32_t)(ab + (done ? 0 : r));
+    const bool idle = r >= K || lane >= DG_ERPW;   // idle lanes stay in the wave (shuffles, votes)
+    const uint32_t a = (uint32_t)(ab + (idle ? 0 : r));
     const uint32_t blen = p.tlen[t];
     const uint32_t exitpos = blen + 1;
     if ((blockIdx.z << p.emit_shift) > exitpos) return;      // the grid is sized for the longest target
@@ -1043,30 +1046,33 @@ __global__ __launch_bounds__(64) void k_emit(DgParams p) {
     const uint32_t *bid = p.bid + bv, *gbase = p.gbase + bv;
     uint32_t *Am = p.matA + p.mat_base[t];
     uint32_t *Dm = p.matD + p.mat_base[t];
-    const uint32_t *Cm = p.matC + p.matc_base[t] + (uint64_t)(done ? 0 : r) * p.matc_stride[t];   // the read's row
+    const uint32_t *Cm = p.matC + p.matc_base[t] + (uint64_t)(idle ? 0 : r) * p.matc_stride[t];   // the read's row
     uint32_t *pool = p.pool + p.pool_base[t];
     DgNode *ndt = p.nodes + nb;
     // pool words / vertex records / matrix cells: uniform base + 32-bit byte offset (see k_merge)
 #define DG_EPW(OFF) (*reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(pool) + (((uint32_t)(OFF)) << 2)))
 #define DG_ECELL(M, POS) (*reinterpret_cast<uint32_t *>(reinterpret_cast<char *>((M) + (uint64_t)(POS) * K) + (r << 2)))
     const uint16_t *buf = p.norm + p.norm_off[a];
-    const uint32_t lo = done ? 0 : p.n_lo[a], hi = done ? 0 : p.n_hi[a];
-    uint32_t bbpos = done ? 0xFFFFFFFFu : p.n_start[a];
+    const uint32_t lo = idle ? 0 : p.n_lo[a], hi = idle ? 0 : p.n_hi[a];
+    // What a lane carries along its read lives in vector registers, flags included: a boolean that differs from lane to
+    // lane is a lane mask to the compiler, and every such mask that lives across a branch costs three scalar instructions
+    // at every join behind it -- with `done`, `own`, `prev_bb`, `have`, `ins_open` ... kept that way a third of the
+    // kernel's instructions were mask bookkeeping (2.7 G scalar against 1.6 G vector instructions per launch).
+    uint32_t bbpos = idle ? DG_EDONE : p.n_start[a];   // the backbone position the lane's next column belongs to; DG_EDONE: nothing (left) here
     uint32_t prev = 0;            // vertex id of the previous vertex on the read's path
     uint32_t prev_pos = 0;        // its backbone position (_bbMap for an inserted vertex)
-    bool prev_bb = true;
-    bool own = true;              // prev was created by this wave (the enter vertex: by the read's first stretch)
+    uint32_t fl = DG_EF_BB | DG_EF_OWN;   // prev is a backbone vertex; prev was created by this wave (the enter vertex: by the read's first stretch)
     uint32_t i = lo;
     const uint32_t P0 = blockIdx.z << p.emit_shift, P1 = P0 + (1u << p.emit_shift);
-    const bool rvalid = r < K && lane < DG_ERPW;   // the lane has a read of its own (its matC row is its own)
+    const bool rvalid = !idle;                     // the lane has a read of its own (its matC row is its own)
     bool pfx_entry = false;
-    if (!done) {
-        if (bbpos >= P1) done = true;                       // the read starts in a later stretch
+    if (!idle) {
+        if (bbpos >= P1) bbpos = DG_EDONE;                  // the read starts in a later stretch
         else if (bbpos < P0) {
             const uint32_t ck = p.ckpt[p.ck_base[a] + blockIdx.z];
-            if (ck == DG_CK_NONE || ck >= hi) done = true;  // the read ended in an earlier stretch
+            if (ck == DG_CK_NONE || ck >= hi) bbpos = DG_EDONE;  // the read ended in an earlier stretch
             else {
-                i = ck; bbpos = P0; own = false;
+                i = ck; bbpos = P0; fl = DG_EF_BB;
                 // the vertex in front: back over deletion columns (and columns addAln skips)
                 uint32_t x = ck, d = 0;
                 while (x > lo) {
@@ -1081,7 +1087,7 @@ __global__ __launch_bounds__(64) void k_emit(DgParams p) {
                             const uint32_t c1 = r + 1 < K ? Cm[p.matc_stride[t] + prev_pos] : p.gcount[bv + prev_pos];
                             prev = gbase[prev_pos] + c1 - 1u;
                         }
-                        prev_bb = false;
+                        fl = 0;
                         break;
                     }
                 }
@@ -1124,8 +1130,8 @@ __global__ __launch_bounds__(64) void k_emit(DgParams p) {
     // among inserted vertices is id - position)
 #define DG_DEPART(NXT)                                                       \
     do {                                                                     \
-        if (!own) break;                                                     \
-        if (prev_bb) {                                                       \
+        if (!(fl & DG_EF_OWN)) break;                                        \
+        if (fl & DG_EF_BB) {                                                 \
             if (prev_pos >= pos0) s_D[(prev_pos - pos0) * 64 + lane] = (NXT) + 1u;   \
             else DG_ECELL(Dm, prev_pos) = (NXT) + 1u;                \
         } else {                                                             \
@@ -1140,7 +1146,7 @@ __global__ __launch_bounds__(64) void k_emit(DgParams p) {
     // its is there yet, and goes on to its end (and past position tlen while a read still has to
     // reach the exit: every read ends by position tlen + 1).
     uint32_t pos0 = P0;                            // a multiple of 16
-    while (pos0 < P1 && (pos0 <= blen || (!__all(done) && pos0 <= blen + 2u * DG_EB))) {
+    while (pos0 < P1 && (pos0 <= blen || (!__all(bbpos == DG_EDONE) && pos0 <= blen + 2u * DG_EB))) {
         // backbone ids of the batch: bid[pos0 .. pos0+15] (reads past tlen+1 stay inside the arena)
         uint32_t bidv[DG_EB];
         {
@@ -1175,32 +1181,31 @@ __global__ __launch_bounds__(64) void k_emit(DgParams p) {
                 cmv[j] = __ballot(x != 0u) ? dg_wave_excl(x, lane) : 0u;
             }
         }
-        if (!done && i < hi && (i - c_base) + 24u > DG_ECOLS) DG_STAGE(i);
+        if (bbpos != DG_EDONE && i < hi && (i - c_base) + 24u > DG_ECOLS) DG_STAGE(i);
         uint32_t acell[DG_EB];
 #pragma unroll
         for (int j = 0; j < DG_EB; j++) { acell[j] = 0; s_D[j * 64 + lane] = 0; }
-        bool exit_cell = false;
-        uint32_t exit_val = 0;
+        uint32_t exit_val = 0;                      // (not 0: the arrival cell of the exit vertex)
 #pragma unroll
         for (int j = 0; j < DG_EB; j++) {
             const uint32_t pos = pos0 + j;
-            bool f_closed = false;
             uint32_t f_apos = 0, f_key = 0, f_first = 0;
-            if (!done && bbpos == pos && pos < P1) {
+            asm volatile("" : "+v"(fl));            // (the flags stay a register: no lane masks rebuilt from them across positions)
+            if (bbpos == pos && pos < P1) {
                 // columns in front of this position that do not advance the backbone cursor:
                 // insertions (AlnGraphBoost.cpp:95-104); raw columns that match no branch are skipped
-                uint32_t ins_id = 0;
-                bool ins_open = false, have = false;
+                uint32_t ins_id = 0;                  // next id of the read's insertion run here (0: no insertion column yet)
+                uint32_t kacc = 0;                    // its bases
                 uint16_t c = 0;
                 f_apos = prev_pos;
-                const bool f_anc_ok = prev_bb && own && pos - prev_pos < 16u;
-                while (i < hi) {
-                    DG_COLUMN(i, c);
+                const bool f_anc_ok = fl == (DG_EF_BB | DG_EF_OWN) && pos - prev_pos < 16u;
+                for (;;) {
+                    if (i < hi) DG_COLUMN(i, c);
                     const uint8_t qb = DG_Q(c), tb = DG_T(c);
-                    if (qb == tb || qb == DG_GAP) { have = true; break; }
+                    if (i >= hi || qb == tb || qb == DG_GAP) break;
                     if (tb == DG_GAP) {
-                        if (!ins_open) { ins_open = true; ins_id = gbv[j] + cmv[j]; f_first = ins_id; }
-                        f_key = (f_key << 8) | qb;
+                        if (!ins_id) { ins_id = gbv[j] + cmv[j]; f_first = ins_id; }
+                        kacc = (kacc << 8) | qb;
                         const uint32_t id = ins_id++;
                         const uint32_t rk = id - bbpos;   // bbpos backbone vertices precede group bbpos
                         DgNode nd;
@@ -1211,27 +1216,26 @@ __global__ __launch_bounds__(64) void k_emit(DgParams p) {
                         *reinterpret_cast<DgNode *>(reinterpret_cast<char *>(ndt) + (id << 5)) = nd;
                         DG_EPW(3u * rk + 2u) = prev;
                         DG_DEPART(id);
-                        prev = id; prev_pos = bbpos; prev_bb = false; own = true;
+                        prev = id; prev_pos = bbpos; fl = DG_EF_OWN;
                     }
                     i++;
                 }
-                if (!have) {                              // :106 the read ends: edge to the exit vertex
+                if (i >= hi) {                            // :106 the read ends: edge to the exit vertex
                     // (behind nothing but deletions of this stretch the earlier stretch's look-ahead
                     // has been here already)
-                    exit_cell = own; exit_val = prev + 1u;
+                    exit_val = (fl & DG_EF_OWN) ? prev + 1u : 0u;
                     const uint32_t ex = bid[exitpos];
                     DG_DEPART(ex);
-                    done = true;
+                    bbpos = DG_EDONE;
                 } else {
                     const uint8_t qb = DG_Q(c), tb = DG_T(c);
                     if (qb == tb) {                       // match (:75-85)
                         const uint32_t cur = bidv[j];
                         acell[j] = ((uint32_t)tb << 25) | (prev + 1u);
                         // (a chain of one to three vertices between a backbone vertex and this match: dg_emit_fold)
-                        if (f_anc_ok && f_key != 0u && f_key < (1u << 24)) f_key |= (pos - f_apos) << 24; else f_key = 0;
-                        f_closed = true;
+                        if (f_anc_ok && kacc != 0u && kacc < (1u << 24)) f_key = kacc | ((pos - f_apos) << 24);
                         DG_DEPART(cur);
-                        prev = cur; prev_pos = bbpos; prev_bb = true; own = true;
+                        prev = cur; prev_pos = bbpos; fl = DG_EF_BB | DG_EF_OWN;
                     } else {                              // deletion (:87-93)
                         acell[j] = ((uint32_t)tb << 25) | DG_CELL_DEL;
                     }
@@ -1241,12 +1245,11 @@ __global__ __launch_bounds__(64) void k_emit(DgParams p) {
             }
             if (p.fold) {
                 // chains that closed at this position, two or more of them: fold the duplicates (dg_emit_fold)
-                if (!f_closed) f_key = 0;
                 const unsigned long long em = __ballot(f_key != 0u);
                 if (em & (em - 1ull)) {
                     uint32_t fn;
-                    const bool vic = dg_emit_fold(em, f_key, f_first, pos, ndt, pool, &fn, lane);
-                    if (vic || fn) {
+                    const uint32_t vic = dg_emit_fold(em, f_key, f_first, pos, ndt, pool, &fn, lane);
+                    if (vic | fn) {
                         // the departure cell of the vertex in front: the survivor's carries the reads folded into its
                         // chain (k_lists counts the out-edge with them), a victim's is empty
                         const uint32_t dv = vic ? 0u : (f_first + 1u) | ((fn - 1u) << 25);
@@ -1273,14 +1276,14 @@ __global__ __launch_bounds__(64) void k_emit(DgParams p) {
                     if (pos > 0 || dv) DG_ECELL(Dm, pos) = dv;
                 }
             }
-            if (exit_cell) DG_ECELL(Am, exitpos) = exit_val;
+            if (exit_val) DG_ECELL(Am, exitpos) = exit_val;
         }
         pos0 += DG_EB;
     }
     // the read goes on beyond the stretch: the departure of the last vertex created here needs
     // the next vertex of the path (the next stretch's wave writes that vertex's arrival side)
     {
-        const bool ahead = !done && own;
+        const bool ahead = bbpos != DG_EDONE && (fl & DG_EF_OWN);
         uint32_t q = bbpos, nxt = 0;
         bool found = false, pfx_next = false;
         if (ahead) {
