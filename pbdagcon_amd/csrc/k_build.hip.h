@@ -185,11 +185,13 @@ __device__ inline DgChunkRun dg_norm_run(const uint8_t *q, const uint8_t *t, con
     // finished columns collect in a 128-bit shift register and leave 8 at a time (out is
     // 16-byte aligned): one store request instead of eight
     uint32_t o0 = 0, o1 = 0, o2 = 0, o3 = 0;
-    bool in_done = false, dirty = false;
+    // (flags that differ from lane to lane are kept as integers in vector registers, not as booleans: see k_emit)
+    uint32_t in_done = 0, dirty = 0, overflow = 0;
     for (;;) {
+        asm volatile("" : "+v"(in_done), "+v"(dirty));
         // ---- refill: Alignment.cpp:142-159 on the next (up to) 16 input columns ----
+        if (!in_done && (e - i) + 32u > NW) { overflow = 1; break; }
         if (!in_done) {
-            if ((e - i) + 32u > NW) { r.overflow = true; break; }
             uint32_t take = len - ip;
             if (take > 16u) take = 16u;
             if (ip < k1 && take > k1 - ip) take = k1 - ip;  // land on the chunk's end exactly
@@ -198,12 +200,12 @@ __device__ inline DgChunkRun dg_norm_run(const uint8_t *q, const uint8_t *t, con
                 uint8_t qb_ = (QB), tb_ = (TB);                                \
                 if (qb_ == '.') qb_ = DG_GAP;                                  \
                 if (tb_ == '.') tb_ = DG_GAP;                                  \
-                if (qb_ != tb_ && qb_ != DG_GAP && tb_ != DG_GAP) {            \
-                    DG_W(e) = DG_COL(DG_GAP, tb_); e++;                        \
-                    DG_W(e) = DG_COL(qb_, DG_GAP); e++;                        \
-                } else {                                                       \
-                    DG_W(e) = DG_COL(qb_, tb_); e++;                           \
-                }                                                              \
+                /* a mismatch becomes (-, t) (q, -): no branch -- the second slot is written whatever the column is */ \
+                /* (the next column overwrites it; the refill has 32 free slots for its 16 columns) */                   \
+                const bool mm_ = qb_ != tb_ && qb_ != DG_GAP && tb_ != DG_GAP; \
+                DG_W(e) = mm_ ? DG_COL(DG_GAP, tb_) : DG_COL(qb_, tb_);        \
+                DG_W(e + 1u) = DG_COL(qb_, DG_GAP);                            \
+                e += mm_ ? 2u : 1u;                                            \
             } while (0)
             if (take == 16u && (((uintptr_t)(q + ip)) & 15u) == 0) {
                 // the common case, unrolled: bytes come out of the two 16-byte registers with
@@ -233,7 +235,7 @@ __device__ inline DgChunkRun dg_norm_run(const uint8_t *q, const uint8_t *t, con
 #undef DG_EXPAND
             ip += take;
             if (ip == k1) e_end = e;
-            if (ip == len) in_done = true;
+            if (ip == len) in_done = 1;
         }
         // ---- Alignment.cpp:165-198 push gaps to the right, as far as the window reaches.
         // jt / jq only move forward (a column left of a cursor is never turned back into
@@ -244,23 +246,23 @@ __device__ inline DgChunkRun dg_norm_run(const uint8_t *q, const uint8_t *t, con
             if (i + 1 == e && !in_done) break;
             const uint16_t c = DG_W(i);
             uint8_t qi = DG_Q(c), ti = DG_T(c);
-            bool more = false;
+            uint32_t more = 0;
             if (i + 1 < e) {
                 if (ti == DG_GAP) {
                     if (jt <= i) jt = i + 1;
                     while (jt < e && DG_T(DG_W(jt)) == DG_GAP) jt++;
                     if (jt < e) {
                         const uint16_t cj = DG_W(jt);
-                        if (DG_T(cj) == qi) { ti = qi; DG_W(jt) = DG_COL(DG_Q(cj), DG_GAP); dirty |= jt >= e_end; }
-                    } else if (!in_done) more = true;
+                        if (DG_T(cj) == qi) { ti = qi; DG_W(jt) = DG_COL(DG_Q(cj), DG_GAP); dirty |= (uint32_t)(jt >= e_end); }
+                    } else if (!in_done) more = 2;
                 }
                 if (!more && qi == DG_GAP) {
                     if (jq <= i) jq = i + 1;
                     while (jq < e && DG_Q(DG_W(jq)) == DG_GAP) jq++;
                     if (jq < e) {
                         const uint16_t cj = DG_W(jq);
-                        if (DG_Q(cj) == ti) { qi = ti; DG_W(jq) = DG_COL(DG_GAP, DG_T(cj)); dirty |= jq >= e_end; }
-                    } else if (!in_done) more = true;
+                        if (DG_Q(cj) == ti) { qi = ti; DG_W(jq) = DG_COL(DG_GAP, DG_T(cj)); dirty |= (uint32_t)(jq >= e_end); }
+                    } else if (!in_done) more = 2;
                 }
             }
             if (more) { DG_W(i) = DG_COL(qi, ti); break; }
@@ -283,7 +285,7 @@ __device__ inline DgChunkRun dg_norm_run(const uint8_t *q, const uint8_t *t, con
         const uint32_t v = word == 0 ? o0 : word == 1 ? o1 : word == 2 ? o2 : o3;
         out[x] = (uint16_t)((sh & 1u) ? v >> 16 : v & 0xffffu);
     }
-    r.w = w; r.tb = tb; r.dirty = dirty; r.badchar = (badw & 0x80808080u) != 0;
+    r.w = w; r.tb = tb; r.dirty = dirty != 0; r.overflow = overflow != 0; r.badchar = (badw & 0x80808080u) != 0;
     return r;
 }
 
