@@ -99,6 +99,7 @@ struct Ctx {
     int emit2 = 0;                                 // addAln with a thread per column (k_emit2.hip.h; DAGCON_EMIT2)
     uint32_t max_len = 0, bs_stride = 0;
     DevBuf d_matK, d_bbstart;
+    int bp_lane = 1, bl_stk = -1;                  // full-span bestPath: a lane per piece (k_bp_sweep_l; DAGCON_BP_LANE=0: a wave per piece, k_bp_sweep); DAGCON_BP_LANE_STACK: test knob
     int bp_fused = 1;                              // partial-span bestPath: one (A, B) sweep + vertex-parallel kernels (DAGCON_BP_FUSED=0: three sweeps)
     uint32_t align_dropped = 0;                    // records of the last dagcon_align / dagcon_consensus_pre the band could not align
     int emit_scan = 1;                             // k_emit takes the prefix over the reads itself (DAGCON_EMIT_SCAN=0: k_groups, as for deeper targets)
@@ -307,6 +308,7 @@ void fill_params(Ctx *c, DgParams &p) {
 #endif
     p.emit2 = c->emit2 ? 1u : 0u; p.matK = (uint8_t *)c->d_matK.p; p.bbstart = (uint32_t *)c->d_bbstart.p; p.bs_stride = c->bs_stride;
     p.bp_fused = c->bp_fused ? 1u : 0u; p.score_b = (float *)c->d_score_b.p;
+    p.bp_lane = c->bp_lane ? 1u : 0u; p.bl_stk = c->bl_stk >= 0 && c->bl_stk < DG_BL_STK ? (uint32_t)c->bl_stk : (uint32_t)DG_BL_STK;
     p.emit_scan = (c->emit_scan && c->max_k <= 64u && !c->emit2) ? 1u : 0u;
     p.fold = (c->fold && !(c->opts.flags & DAGCON_FLAG_STOP_AFTER_BUILD)) ? 1u : 0u;
     p.q_kmax = c->use_q && !c->opts.max_segments && !c->seg_env && c->max_k > DQ_KMAX ? DQ_KMAX : 0u;
@@ -435,6 +437,8 @@ int launch_all(Ctx *c) {
             hipLaunchKernelGGL(k_bp_defer, dim3(c->T), dim3(64), 0, s, p);
             hipLaunchKernelGGL(k_bp_walk_g, dim3(c->T * c->bp_max), dim3(64), 0, s, p);
         } else {
+            // a lane per piece first; the wave-per-piece sweep then takes the pieces a lane gave up (deep recursion)
+            if (p.bp_lane) hipLaunchKernelGGL(k_bp_sweep_l, dim3((c->T * c->bp_max + 7u) / 8u), dim3(64), 0, s, p);
             hipLaunchKernelGGL(k_bp_sweep, dim3(c->T * c->bp_max), dim3(64), 0, s, p);
             hipLaunchKernelGGL(k_bp_check, dim3(c->T), dim3(64), 0, s, p);
             hipLaunchKernelGGL(k_bp_walk, dim3(c->T * c->bp_max), dim3(64), 0, s, p);
@@ -491,6 +495,8 @@ int dagcon_create(const dagcon_opts *opts, dagcon_ctx **out) {
     if (const char *e = getenv("DAGCON_NF2")) c->nf2 = atoi(e) != 0;
     if (const char *e = getenv("DAGCON_EMIT_SCAN")) c->emit_scan = atoi(e) != 0;
     if (const char *e = getenv("DAGCON_BP_FUSED")) c->bp_fused = atoi(e) != 0;
+    if (const char *e = getenv("DAGCON_BP_LANE")) c->bp_lane = atoi(e) != 0;
+    if (const char *e = getenv("DAGCON_BP_LANE_STACK")) c->bl_stk = atoi(e);
 #ifdef DG_EXPERIMENTS
     if (const char *e = getenv("DAGCON_EMIT2")) c->emit2 = atoi(e) != 0;
 #endif

@@ -488,6 +488,8 @@ __global__ __launch_bounds__(64) void k_bp_sweep(DgParams p) {
     const int N = (int)p.n_nodes[t];
     const int c_bot = (int)crow[1 + seg];
     const int c_top = seg + 1 < nseg ? (int)crow[2 + seg] : -1;
+    // (p.bp_lane: k_bp_sweep_l has been over every piece; what it gave up is marked)
+    if (p.bp_lane && !(p.bp_stat[2 * (uint64_t)blockIdx.x] < 0.0f)) return;
     float amax = 0.0f;
     bool bad = false, stuck = false;
     dg_bp_sweep(S, p.nodes + nb, p.best + nb, p.score + nb, p.pool + p.pool_base[t], p.bp_tt + nb,
@@ -500,6 +502,214 @@ __global__ __launch_bounds__(64) void k_bp_sweep(DgParams p) {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     const float a = p.score[nb + c_bot].x;                        // this segment's first vertex, relative to c_top
     if (lane == 0) { p.bp_stat[2 * (uint64_t)blockIdx.x] = amax; p.bp_stat[2 * (uint64_t)blockIdx.x + 1] = a; }
+}
+
+// ---- the same recurrence with a ROW of eight lanes per piece (full-span pileups, round 3) ----------------------------
+// k_bp_sweep gives a wave to a piece and scores one vertex at a time with the out-edges on its lanes: 1.5 lanes busy, 116
+// instructions issued per live vertex, and the kernel is bound by exactly that.  Here a wave sweeps eight pieces at once,
+// one per row of eight lanes (as k_merge_q does for the merge): a step scores one vertex per row -- the vertex's record and
+// final flag (the same address on the row's lanes: one request), its out-edges one per lane, their successors' scores and
+// target terms one per lane, then the first maximum in list order with a strict '>' (AlnGraphBoost.cpp:399-416) as a
+// maximum over the row and the lowest lane that holds it.  The fp32 operations per edge are dg_bp_sweep's, so are the
+// bits.  A successor that has no score yet (an edge the merge turned around: 6 % of the live vertices have one) is scored
+// first, from a small stack of the row's own in LDS; a row that runs out of stack, meets a vertex with more out-edges than
+// it has lanes, or spends its step budget marks its piece (bp_stat < 0) and k_bp_sweep does that piece over.
+// Scores are relative to the piece's upper cut, as there (k_bp_check verifies the exactness of that from bp_stat).
+// What steers a row lives in vector registers (see k_emit for why).
+// (A LANE per piece -- 64 pieces a wave, plain sequential code -- was built first: exact, and 8 - 14 ms instead of 4.7:
+// every load of a wave is 64 requests for 64 different lines, and the vector cache fills at a line every other clock.)
+#define DG_BL_STK 16
+#define DG_BRW 8                   // lanes of a row
+#define DG_BRR 32                  // a row's ring of finished vertices in LDS: (id, score, target term) of id & 31
+#define DG_BRP 8                   // finished vertices a row holds back before it writes them to HBM, one per lane
+__device__ __forceinline__ uint32_t dbr_ballot(bool q) { return (uint32_t)((__ballot(q) >> (threadIdx.x & (64u - DG_BRW))) & 0xffull); }
+// maximum over the row's eight lanes: two quad permutations and the half-row mirror, in registers (DPP)
+__device__ __forceinline__ float dbr_max(float m) {
+    m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m), 0xB1, 0xf, 0xf, true)));     // quad_perm [1,0,3,2]
+    m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m), 0x4E, 0xf, 0xf, true)));     // quad_perm [2,3,0,1]
+    m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m), 0x141, 0xf, 0xf, true)));    // row_half_mirror
+    return m;
+}
+__global__ __launch_bounds__(64) void k_bp_sweep_l(DgParams p) {
+    constexpr int ROWS = 64 / DG_BRW;
+    __shared__ int s_stk[ROWS * DG_BL_STK];
+    __shared__ int s_rtag[ROWS * DG_BRR];
+    __shared__ float s_rsc[ROWS * DG_BRR], s_rtt[ROWS * DG_BRR];
+    __shared__ int s_pid[ROWS * DG_BRP], s_pbd[ROWS * DG_BRP];
+    __shared__ float s_pmx[ROWS * DG_BRP];
+    if (dg_failed(p)) return;
+    const int l = threadIdx.x & (DG_BRW - 1);
+    const uint32_t row = threadIdx.x / DG_BRW;
+    const uint32_t piece = blockIdx.x * (uint32_t)ROWS + row;
+    const uint32_t t = piece / p.bp_max, seg = piece % p.bp_max;
+    if (t >= p.T || dg_tskip(p, t)) return;
+    const uint32_t *crow = p.cuts_bp + (uint64_t)t * (p.bp_max + 2u);
+    const uint32_t nseg = crow[0];
+    if (seg >= nseg) return;
+    const uint64_t nb = p.node_base[t];
+    const DgNode *nd = p.nodes + nb;
+    float2 *score = p.score + nb;
+    int32_t *best = p.best + nb;
+    const uint32_t *pool = p.pool + p.pool_base[t];
+    const float *tt = p.bp_tt + nb;
+    const int N = (int)p.n_nodes[t];
+    const int c_bot = (int)crow[1 + seg];
+    const int c_top = seg + 1 < nseg ? (int)crow[2 + seg] : -1;
+    const int v_top = c_top >= 0 ? c_top - 1 : N - 1;
+    int *stk = s_stk + row * DG_BL_STK;
+    int *rtag = s_rtag + row * DG_BRR;
+    float *rsc = s_rsc + row * DG_BRR, *rtt = s_rtt + row * DG_BRR;
+    int *pid = s_pid + row * DG_BRP, *pbd = s_pbd + row * DG_BRP;
+    float *pmx = s_pmx + row * DG_BRP;
+    for (int i = l; i < DG_BRR; i += DG_BRW) rtag[i] = -1;
+    const int stk_cap = (int)p.bl_stk;
+    float amax = 0.0f;
+    int bad = 0;
+    uint32_t guard = 0;
+    const uint32_t guard_max = 64u * (uint32_t)(v_top - c_bot + 1) + 1000000u;
+    // What a step needs of its vertex x -- out_len | in_len, base | flags, out_off, the final flag of its score, its own
+    // target term -- is five words at three places: lanes 0 .. 4 of the row fetch one each (one load instruction), and the
+    // row reads them off those lanes.
+#define DBR_GATHER(X, OUT)                                                                               \
+    do {                                                                                                 \
+        const char *a_ = reinterpret_cast<const char *>(&nd[X]) + (l == 1 ? 4 : l == 2 ? 16 : 0);       \
+        if (l == 3) a_ = reinterpret_cast<const char *>(&score[X]) + 4;                                  \
+        if (l == 4) a_ = reinterpret_cast<const char *>(&tt[X]);                                         \
+        OUT = *reinterpret_cast<const uint32_t *>(a_);                                                   \
+    } while (0)
+#define DBR_DECODE(G, LOX, LOY, OFF, FIN, TTN)                                                           \
+    do {                                                                                                 \
+        LOX = (uint32_t)__shfl((int)(G), 0, DG_BRW); LOY = (uint32_t)__shfl((int)(G), 1, DG_BRW);         \
+        OFF = (uint32_t)__shfl((int)(G), 2, DG_BRW);                                                     \
+        FIN = __int_as_float(__shfl((int)(G), 3, DG_BRW)); TTN = __int_as_float(__shfl((int)(G), 4, DG_BRW)); \
+    } while (0)
+#define DBR_EDGES(LOX, LOY, OFF, D, CNT)                                                                 \
+    do {                                                                                                 \
+        D = c_top; CNT = 0;                                                                              \
+        if (l < (int)((LOX) & 0xffffu) && !(((LOY) >> 8) & DG_NF_DELETED)) {                             \
+            D = (int)pool[(OFF) + 2u * (uint32_t)l]; CNT = (int)pool[(OFF) + 2u * (uint32_t)l + 1u];     \
+        }                                                                                                \
+    } while (0)
+    // the row's finished vertices go to HBM, one per lane (nobody waits for these stores: the ring has the scores)
+    int npend = 0;
+#define DBR_FLUSH()                                                                                      \
+    do {                                                                                                 \
+        if (l < npend) { const int id_ = pid[l]; score[id_] = make_float2(pmx[l], 1.0f); best[id_] = pbd[l]; } \
+        npend = 0;                                                                                       \
+    } while (0)
+    // The stream runs two steps ahead of itself: while vertex v is scored the out-edges of v - 1 and the record of v - 2
+    // are on their way (c_*: record and edges of vertex cv, the next one of the stream; raw: the words of cv - 1).
+    int v = v_top, n = v_top, sp = 0;
+    int going = v_top >= c_bot ? 1 : 0;
+    int cv = -1, c_d = 0, c_cnt = 0;
+    uint32_t c_lox = 0, c_loy = 0, c_off = 0, raw = 0;
+    float c_fin = 0.0f, c_ttn = 0.0f;
+    if (going) {
+        uint32_t g0;
+        DBR_GATHER(v_top, g0);
+        if (v_top > c_bot) DBR_GATHER(v_top - 1, raw);
+        DBR_DECODE(g0, c_lox, c_loy, c_off, c_fin, c_ttn);
+        DBR_EDGES(c_lox, c_loy, c_off, c_d, c_cnt);
+        cv = v_top;
+    }
+    while (going) {
+        // every row must leave this loop: the work is bounded by (vertices + edges), far below this budget
+        if (++guard > guard_max) { bad = 1; going = 0; continue; }
+        uint32_t lox, loy, out_off;
+        float fin, ttn;
+        int d, cnt;
+        if (n == cv) {
+            // the stream's vertex: everything is at hand; the pipeline moves on
+            lox = c_lox; loy = c_loy; out_off = c_off; fin = c_fin; ttn = c_ttn; d = c_d; cnt = c_cnt;
+            // (copied here and now: the loads below then land in the c_* registers themselves, and nobody has to wait for
+            // them before the next step)
+            asm volatile("" : "+v"(lox), "+v"(loy), "+v"(out_off), "+v"(fin), "+v"(ttn), "+v"(d), "+v"(cnt));
+            if (cv > c_bot) {
+                DBR_DECODE(raw, c_lox, c_loy, c_off, c_fin, c_ttn);
+                DBR_EDGES(c_lox, c_loy, c_off, c_d, c_cnt);
+                cv--;
+                if (cv > c_bot) DBR_GATHER(cv - 1, raw);
+            } else cv = -1;
+        } else {
+            // a vertex off the stack (or the stream's vertex once more, behind one): fetched now
+            uint32_t g;
+            DBR_GATHER(n, g);
+            DBR_DECODE(g, lox, loy, out_off, fin, ttn);
+            DBR_EDGES(lox, loy, out_off, d, cnt);
+            asm volatile("" : "+v"(d), "+v"(cnt));            // (waited for here: behind the join nothing of this path is in flight)
+        }
+        const int out_len = (int)(lox & 0xffffu);
+        // (a final flag fetched ahead may be out of date -- the vertex was scored since, off the stack: the ring knows, and
+        // if it has forgotten the vertex is scored once more, to the same result)
+        const int live = (int)!(fin >= 1.0f) & (int)!((loy >> 8) & DG_NF_DELETED) & (int)(rtag[n & (DG_BRR - 1)] != n);
+        int next = 1;                                    // 1: n is done with (scored, or nothing to score): the row moves on
+        if (live) {
+            if (out_len > DG_BRW) { bad = 1; going = 0; continue; }
+            // ---- its out-edges, one per lane; their successors' scores and target terms: the ring, else HBM ----
+            const bool valid = l < out_len;
+            const int x = d & (DG_BRR - 1);
+            const bool ref = d == c_top;                     // the piece's reference point: score 0
+            const bool hit = valid && rtag[x] == d;
+            float sc = rsc[x], tv = rtt[x];
+            int have = (int)hit;
+            if (dbr_ballot(valid && !hit)) {
+                // (what the row holds back goes out first, and is waited for: HBM then has every score the row has made)
+                DBR_FLUSH();
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                if (valid && !hit) {
+                    const float2 sg = score[d];
+                    tv = tt[d];
+                    sc = sg.x;
+                    have = (int)(sg.y >= 1.0f);
+                    asm volatile("" : "+v"(sc), "+v"(tv), "+v"(have));       // (waited for here, not behind the join)
+                }
+            }
+            if (ref) { sc = 0.0f; have = 1; }
+            const uint32_t miss = dbr_ballot(valid && !have);
+            if (miss) {
+                // a turned-around edge: that successor first, then this vertex again
+                if (sp >= stk_cap) { bad = 1; going = 0; continue; }
+                if (l == 0) stk[sp] = n;
+                sp++;
+                n = __shfl(d, __ffs((int)miss) - 1, DG_BRW);
+                next = 0;
+            } else {
+                const float w = tv == DG_TT_TEN ? -10.0f : (float)cnt - tv;          // :404-408
+                const float ns = w + sc;
+                float mx = 0.0f;                             // no out edge (the exit vertex): score 0, the map default
+                int bd = -1;
+                if (out_len > 0) {
+                    // :399-416 first maximum in list order, strict '>': the row's maximum, the lowest lane that has it
+                    const float m = dbr_max(valid ? ns : -FLT_MAX);
+                    const int f = __ffs((int)dbr_ballot(valid && ns == m)) - 1;
+                    mx = __shfl(ns, f, DG_BRW);
+                    bd = __shfl(d, f, DG_BRW);
+                }
+                if (l == 0) {
+                    pid[npend] = n; pmx[npend] = mx; pbd[npend] = bd;
+                    rtag[n & (DG_BRR - 1)] = n; rsc[n & (DG_BRR - 1)] = mx; rtt[n & (DG_BRR - 1)] = ttn;
+                }
+                npend++;
+                if (npend == DG_BRP) DBR_FLUSH();
+                if (mx > 0.5f * DG_BP_NINF) amax = fmaxf(amax, fabsf(mx));
+            }
+        }
+        if (next) {
+            if (sp > 0) { sp--; n = stk[sp]; }
+            else { v--; n = v; if (v < c_bot) going = 0; }
+        }
+    }
+    DBR_FLUSH();
+#undef DBR_GATHER
+#undef DBR_DECODE
+#undef DBR_EDGES
+#undef DBR_FLUSH
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    const float a = bad ? 0.0f : score[c_bot].x;                      // this piece's first vertex, relative to c_top
+    if (l == 0) {
+        p.bp_stat[2 * (uint64_t)piece] = bad ? -1.0f : amax;
+        p.bp_stat[2 * (uint64_t)piece + 1] = a;
+    }
 }
 
 // ---- exactness check of the segmented sweep, one wave per target -------------------

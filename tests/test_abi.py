@@ -106,4 +106,4 @@ def test_piece_plan_never_gives_an_empty_grid():
     assert out[0] >= 1 and out[3] >= 1
     # configs[1]: 1,000 x 10 kb x 40x keeps the choice the round-2 measurements were made with
     lib.dagcon_debug_plan(1000, 40000, 1000 * 10004, 0, 0, 0, out)
-    assert list(out) == [73, 128, 1, 64]
+    assert list(out) == [49, 128, 1, 64]

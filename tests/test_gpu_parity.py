@@ -1175,11 +1175,14 @@ def test_nothing_reads_what_this_run_did_not_write(seed, rnd, monkeypatch):
                 ctx.close()
 
 
-@pytest.mark.parametrize("knob", ["DAGCON_FOLD", "DAGCON_EMIT_SCAN", "DAGCON_NF2", "DAGCON_BP_FUSED"])
+@pytest.mark.parametrize("knob", ["DAGCON_FOLD", "DAGCON_EMIT_SCAN", "DAGCON_NF2", "DAGCON_BP_FUSED", "DAGCON_BP_LANE",
+                                  "DAGCON_BP_LANE_STACK"])
 def test_round3_paths_and_their_checkers_agree(knob, monkeypatch):
     """Every round-3 path has the path it replaced behind a switch -- the fold (duplicate chains merged by the sweep
     instead), the wave's own prefix over the reads (k_groups instead), k_norm_finish2 (a lane per chunk instead), the
-    one-sweep partial-span bestPath (three sweeps instead).  Both sides of each switch against the oracle: full-span and
+    one-sweep partial-span bestPath (three sweeps instead), the full-span bestPath with a lane per piece (a wave per
+    piece instead; DAGCON_BP_LANE_STACK = 0 / 1: a lane gives its piece up at the first / second turned-around edge in
+    a row, so that the wave-per-piece sweep takes over half-done pieces).  Both sides of each switch against the oracle: full-span and
     partial-span synthetic pileups, adversarial little ones (leading insertions, tiny alphabets), a deep target (more
     than a wave of reads: the k_groups path whatever the switch says)."""
     rng = np.random.default_rng(33)
