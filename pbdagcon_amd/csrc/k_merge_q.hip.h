@@ -22,7 +22,7 @@
 #define DQ_ALL ((uint32_t)((1ull << DQ_W) - 1ull))
 #define DQ_LO ((1u << (DQ_W / 2)) - 1u)   // the lower half of a row: in entries of the one-look path
 #ifndef DQ_RING
-#define DQ_RING 32                   // the youngest queue entries of a row, in LDS
+#define DQ_RING 16                   // the youngest queue entries of a row, in LDS: (id, out_len | in_len << 16, out_off, in_off)
 #endif
 typedef uint32_t qmask;              // one bit per lane of the row
 
@@ -331,7 +331,7 @@ __device__ inline bool dq_merge_in_group(DgGraph &g, int n, uint32_t n_in_off, q
 // One segment [c_start, c_end] of target t, swept by the calling ROW (dg_merge_segment, mode DG_MM_WORKER, no
 // shared lists).  c_end = 0x7fffffff: the segment runs to the exit vertex.
 __device__ __forceinline__ void dq_merge_segment(const DgParams &p, const uint32_t t, const int c_start, const int c_end,
-                                                 int32_t *stk_base, int *s_stk, int *s_ring) {
+                                                 int32_t *stk_base, int *s_stk, int4 *s_ring) {
     const int lane = threadIdx.x & (DQ_W - 1);
     const uint64_t nb = p.node_base[t];
     const uint32_t NT = p.n_nodes[t];
@@ -345,7 +345,10 @@ __device__ __forceinline__ void dq_merge_segment(const DgParams &p, const uint32
     g.sh = 0; g.X = -1; g.sh_tab = nullptr; g.seg = 0; g.lg_cap = 0; g.lg_cnt = nullptr;
     const uint32_t N = (uint32_t)(c_hi - c_start + 1);     // vertices this worker can dequeue
     uint32_t qh = 0, qt = 1;
-    if (lane == 0) { g.queue[0] = c_start; s_ring[0] = c_start; }
+    // (a ring entry carries what the visit needs of its vertex's record when the one who queued the vertex had it at hand
+    // -- lens = -1: not so.  The record of a queued vertex does not change before its visit: whoever could touch its lists
+    // is one of its predecessors, or has one of them for a predecessor, and those have all been visited)
+    if (lane == 0) { g.queue[0] = c_start; s_ring[0] = make_int4(c_start, -1, 0, 0); }
     DQ_FENCE();
     // Two phases per round, so that the rows of a wave spend their time on the same code: (A) every row runs
     // through the visits that merge nothing (one look, the FIFO bookkeeping) until it meets a visit that has a merge
@@ -359,8 +362,10 @@ __device__ __forceinline__ void dq_merge_segment(const DgParams &p, const uint32
     int u = -1;
     for (;;) {
         while (st == DQ_ST_RUN && qh < qt) {
-            if (qt - qh <= DQ_RING) u = s_ring[qh & (DQ_RING - 1)];
-            else u = g.queue[qh];
+            int4 qe = make_int4(0, -1, 0, 0);
+            if (qt - qh <= DQ_RING) qe = s_ring[qh & (DQ_RING - 1)];
+            else qe.x = g.queue[qh];
+            u = qe.x;
             qh++;
             const bool in_only = u == c_end;               // the next segment's worker does the rest of that visit
             if (u < c_start || u > c_hi || (in_only && qh != qt)) {       // cannot happen (see k_cuts)
@@ -370,18 +375,25 @@ __device__ __forceinline__ void dq_merge_segment(const DgParams &p, const uint32
                 const bool skip_in = c_start != 0 && u == c_start;        // the previous segment's worker merges in[u]
                 // (k_merge asks for the next vertex's record before this visit's stores go out; here the 8 registers that
                 // takes cost more, in waves per SIMD, than the round trip: 17.3 ms with, 16.1 without at configs[1])
-                const uint4 ul = dg_lo16(&DG_NV(g, u)), uh = dg_hi16(&DG_NV(g, u));
-                const int eff_in = skip_in ? 0 : DG_H_INLEN(ul), eff_out = in_only ? 0 : DG_H_OUTLEN(ul);
+                // u's lens and list offsets: from the ring (the visit that queued u had just read them), else from its record
+                uint32_t u_lens = (uint32_t)qe.y, u_out = (uint32_t)qe.z, u_inn = (uint32_t)qe.w;
+                if (qe.y == -1) {
+                    const uint4 ul = dg_lo16(&DG_NV(g, u)), uh = dg_hi16(&DG_NV(g, u));
+                    u_lens = ul.x; u_out = DG_H2_OUTOFF(uh); u_inn = DG_H2_INOFF(uh);
+                }
+                const int eff_in = skip_in ? 0 : (int)(u_lens >> 16), eff_out = in_only ? 0 : (int)(u_lens & 0xffffu);
                 if (eff_in > DQ_W / 2 || eff_out > DQ_W / 2) st = DQ_ST_NEED;
                 else {
                     const bool is_in = lane < DQ_W / 2;
                     const int idx = lane & (DQ_W / 2 - 1);
                     const bool valid = is_in ? idx < eff_in : idx < eff_out;
-                    const uint32_t ea = is_in ? DG_H2_INOFF(uh) + (uint32_t)idx : DG_H2_OUTOFF(uh) + 2u * (uint32_t)idx;
+                    const uint32_t ea = is_in ? u_inn + (uint32_t)idx : u_out + 2u * (uint32_t)idx;
                     int nbr = 0;
                     if (valid) nbr = (int)DG_PW(g, ea);
                     uint4 h = make_uint4(0, 0, 0, 0);
+                    uint2 ho = make_uint2(0, 0);                  // out_off, in_off of an out-neighbour: for the ring, should this visit queue it
                     if (valid) h = dg_lo16(&DG_NV(g, nbr));
+                    if (valid && !is_in) ho = *(reinterpret_cast<const uint2 *>(&DG_NV(g, nbr)) + 2);
                     // in lanes: out_len == 1 (low half of h.x), out lanes: in_len == 1 (high half)
                     const qmask cand = dq_ballot(valid && ((h.x >> (is_in ? 0u : 16u)) & 0xffffu) == 1u);
                     // a merge group = two candidates of one side with the same base
@@ -406,7 +418,7 @@ __device__ __forceinline__ void dq_merge_segment(const DgParams &p, const uint32
                         if (live) DG_NV(g, nbr).pending = pend;
                         if (live && pend == 0) {
                             const uint32_t pos = qt + (uint32_t)__popc(rm & DQ_LT(lane));
-                            if (pos < N) { g.queue[pos] = nbr; s_ring[pos & (DQ_RING - 1)] = nbr; }
+                            if (pos < N) { g.queue[pos] = nbr; s_ring[pos & (DQ_RING - 1)] = make_int4(nbr, (int)h.x, (int)ho.x, (int)ho.y); }
                         }
                         qt += (uint32_t)__popc(rm);
                         if (qt > N) { dq_fail(g, DG_E_INTERNAL, lane); st = DQ_ST_END; }
@@ -492,7 +504,7 @@ __device__ __forceinline__ void dq_merge_segment(const DgParams &p, const uint32
             const qmask rm = dq_ballot(valid && pend == 0);
             if (valid && pend == 0) {
                 const uint32_t pos = qt + (uint32_t)__popc(rm & DQ_LT(lane));
-                if (pos < N) { g.queue[pos] = d; s_ring[pos & (DQ_RING - 1)] = d; }
+                if (pos < N) { g.queue[pos] = d; s_ring[pos & (DQ_RING - 1)] = make_int4(d, -1, 0, 0); }
             }
             qt += (uint32_t)__popc(rm);
             if (qt > N) dq_fail(g, DG_E_INTERNAL, lane);
@@ -511,7 +523,7 @@ __device__ __forceinline__ void dq_merge_segment(const DgParams &p, const uint32
                     gs.nd[v].pending = pend;
                     if (pend == 0) {
                         if (nqt >= N) { dgg_fail(gs, DG_E_INTERNAL); break; }
-                        s_ring[nqt & (DQ_RING - 1)] = v;
+                        s_ring[nqt & (DQ_RING - 1)] = make_int4(v, -1, 0, 0);
                         gs.queue[nqt++] = v;
                     }
                 }
@@ -531,7 +543,7 @@ __device__ __forceinline__ void dq_merge_segment(const DgParams &p, const uint32
 #endif
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DQ_WAVES, DQ_WAVES))) void k_merge_q(DgParams p) {
     __shared__ int s_stk[DQ_ROWS][2 * DQ_IN_STACK];
-    __shared__ int s_ring[DQ_ROWS][DQ_RING];
+    __shared__ int4 s_ring[DQ_ROWS][DQ_RING];
     const uint32_t row = threadIdx.x / DQ_W;
     const uint32_t pair = blockIdx.x * DQ_ROWS + row;
     const uint32_t t = pair / p.seg_max, seg = pair % p.seg_max;
