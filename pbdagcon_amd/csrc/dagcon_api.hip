@@ -37,7 +37,8 @@ struct DevBuf {
 
 // ---- how many pieces the merge / bestPath sweeps of a batch are cut into (host arithmetic only: exported as
 // dagcon_debug_plan so that a CPU test can sweep it; every grid size derived from it is > 0) ----
-#define DQ_KMAX 72u      // reads per target up to which the row sweep (k_merge_q) beats the wave sweep (k_merge)
+#define DQ_KMAX 52u      // reads per target up to which the row sweep (k_merge_q, rows of 8 lanes) beats the wave sweep (k_merge):
+                         // 600 targets x 6 kb at 40x / 50x / 60x / 70x: 6.5 / 8.4 / 11.6 / 20.0 ms against 7.1 / 8.4 / 9.7 / 11.2 (tools/kmax_probe.py)
 struct DgPlanIn { uint32_t T; uint64_t n_alns, sum_bb; uint32_t gcuts, max_segments, min_segment_len, seg_env, merge_q; };
 struct DgPlan { uint32_t seg_max, seg_min, use_q, bp_max; };
 static DgPlan dg_plan_pieces(const DgPlanIn &in) {
@@ -62,8 +63,8 @@ static DgPlan dg_plan_pieces(const DgPlanIn &in) {
     if (in.merge_q && !in.gcuts && pl.seg_max != 1) {
         const uint32_t slots = 1024u * DQ_WAVES;
         if (in.max_segments || in.seg_env) pl.use_q = 1;                            // (the caller's number of pieces)
-        // a row holds 8 + 8 list entries in its one-look path and 16 in the generic one: past ~70 reads per target
-        // too many visits outgrow it (600 targets x 6 kb: 60x 8.9 ms against k_merge's 11.4, 100x 30.6 against 17.8)
+        // a row holds 4 + 4 list entries in its one-look path and 8 in the generic one: past ~50 reads per target
+        // too many visits outgrow it (DQ_KMAX)
         else if (T && in.n_alns <= (uint64_t)DQ_KMAX * T) {
             // pieces a target can give: up to 256, one per 128 positions of the average backbone
             const uint64_t avail = std::min<uint64_t>(256, std::max<uint64_t>(1, in.sum_bb / T / 128));
@@ -107,6 +108,7 @@ struct Ctx {
     int poison = 0;                                // DAGCON_POISON (tests): arenas nobody clears are filled with 0xEE bytes before every run
     int align2 = 0;                                // (make experiments) k_align_adapt2: two pairs per wave, DAGCON_ALIGN2=1
     int fold = 1;                                  // duplicate insertion chains folded by k_emit (DAGCON_FOLD=0: never)
+    int list_q = 0;                                // (make experiments) partial-span worklist by rows, k_merge_list_q: DAGCON_MERGE_LIST_Q=1
     int merge_q = 1, use_q = 0;                    // k_merge_q: four segments per wave (DAGCON_MERGE_Q=0: never); this batch
     uint32_t max_k = 0, max_tlen = 0;
     uint64_t sum_len = 0, sum_bb = 0, mat_cells = 0, blob_bytes = 0;
@@ -396,6 +398,13 @@ int launch_all(Ctx *c) {
             HIPCHK(c, hipMemsetAsync(c->d_seg_done.p, 0, (size_t)c->tile_list_cap * (DG_SH_MAX + 1) * 4, s));
             hipLaunchKernelGGL(k_merge_pro, dim3(c->T), dim3(64), 0, s, p);
             hipLaunchKernelGGL(k_cuts2, dim3(c->T), dim3(64), 0, s, p);
+            // the worklist, a wave per entry (make experiments: eight entries per wave, one per row of eight lanes, k_merge_list_q)
+#ifdef DG_EXPERIMENTS
+            if (c->merge_q && c->list_q && c->max_k <= DQ_KMAX && (uint64_t)c->T * c->seg_max >= DQ_ROWS) {
+                const uint64_t grid = std::min<uint64_t>(1024ull * DQ_WAVES, (uint64_t)c->T * c->seg_max / DQ_ROWS);
+                hipLaunchKernelGGL(k_merge_list_q, dim3((uint32_t)grid), dim3(64), 0, s, p);
+            } else
+#endif
             hipLaunchKernelGGL(k_merge_list, dim3(c->list_grid), dim3(64), 0, s, p);
             hipLaunchKernelGGL(k_merge_fin, dim3(c->T), dim3(64), 0, s, p);
         }
@@ -500,6 +509,7 @@ int dagcon_create(const dagcon_opts *opts, dagcon_ctx **out) {
 #ifdef DG_EXPERIMENTS
     if (const char *e = getenv("DAGCON_EMIT2")) c->emit2 = atoi(e) != 0;
 #endif
+    if (const char *e = getenv("DAGCON_MERGE_LIST_Q")) c->list_q = atoi(e) != 0;
     if (const char *e = getenv("DAGCON_MERGE_Q")) c->merge_q = atoi(e) != 0;     // four segments per wave (k_merge_q.hip.h)
     memset(&c->tm, 0, sizeof c->tm);
     memset(&c->h_st, 0, sizeof c->h_st);

@@ -142,6 +142,7 @@ __device__ inline bool dq_merge_out_group(DgGraph &g, int u, uint32_t u_out_off,
     uint4 hn2 = make_uint4(0, 0, 0, 0);
     if (vic_entry) hn2 = dg_lo16(&DG_NV(g, n2));
     if (dq_ballot(vic_entry && DG_H_INLEN(hn2) > DQ_W)) return false;
+    if (g.sh && dq_ballot(vic_entry && ((hn2.y >> 8) & DG_NF_SHARED))) return false;      // in[exit] is shared: literal path
 
     // ---- nothing has been modified up to here ----
     const int add_cnt = dq_sum_masked(cnt, vm);
@@ -247,6 +248,7 @@ __device__ inline bool dq_merge_in_group(DgGraph &g, int n, uint32_t n_in_off, q
     uint4 hn1 = make_uint4(0, 0, 0, 0);
     if (fl) hn1 = dg_lo16(&DG_NV(g, n1));
     if (dq_ballot(fl && DG_H_OUTLEN(hn1) > DQ_W)) return false;
+    if (g.sh && dq_ballot(fl && ((hn1.y >> 8) & DG_NF_SHARED))) return false;            // a shared out-list: literal path
     const int a_in_len0 = dq_rl(DG_H_INLEN(h), an_lane);
 
     // ---- nothing has been modified up to here ----
@@ -328,27 +330,45 @@ __device__ inline bool dq_merge_in_group(DgGraph &g, int n, uint32_t n_in_off, q
 #define DQ_ST_NEED 1                 // its visit has a merge group or a long list: the generic code
 #define DQ_ST_END 2                  // the segment is done (or has failed)
 
-// One segment [c_start, c_end] of target t, swept by the calling ROW (dg_merge_segment, mode DG_MM_WORKER, no
-// shared lists).  c_end = 0x7fffffff: the segment runs to the exit vertex.
+// One segment [c_start, c_end] of target t, swept by the calling ROW (dg_merge_segment, mode DG_MM_WORKER).
+// c_end = 0x7fffffff: the segment runs to the exit vertex.
+// GC: a segment of k_cuts2 (partial-span pileups, p.gcuts): enter's out-list, exit's in-list and the out-lists of the few
+// vertices flagged DG_NF_SHARED are touched by every segment's worker (the protocol at DgGraph::sh) -- a visit next to one
+// of them goes the reference-literal way, where the protocol lives; exit is nobody's to enqueue; the segment that starts
+// at enter goes on from the queue k_merge_pro left.  me / wlo: the entry's index in the worklist, its target's first.
+template <bool GC>
 __device__ __forceinline__ void dq_merge_segment(const DgParams &p, const uint32_t t, const int c_start, const int c_end,
-                                                 int32_t *stk_base, int *s_stk, int4 *s_ring) {
+                                                 int32_t *stk_base, int *s_stk, int4 *s_ring, const uint32_t me = 0,
+                                                 const uint32_t wlo = 0) {
     const int lane = threadIdx.x & (DQ_W - 1);
     const uint64_t nb = p.node_base[t];
     const uint32_t NT = p.n_nodes[t];
     const bool has_end = c_end != 0x7fffffff;
     const int c_hi = has_end ? c_end : (int)NT - 1;
     DgGraph g;
-    g.nd = p.nodes + nb; g.queue = p.queue + nb + c_start;
+    const bool own_q = GC && c_start == 0;                 // (see DgParams::queue0)
+    g.nd = p.nodes + nb; g.queue = own_q ? p.queue0 + nb : p.queue + nb + c_start;
     g.pool = p.pool + p.pool_base[t]; g.pool_size = p.pool_size[t]; g.pool_top = p.pool_top + t;
     g.stk = stk_base; g.stk_words = p.stk_words;
     g.st = p.st; g.tfail = p.tfail + t; g.t = t; g.err = false;
     g.sh = 0; g.X = -1; g.sh_tab = nullptr; g.seg = 0; g.lg_cap = 0; g.lg_cnt = nullptr;
-    const uint32_t N = (uint32_t)(c_hi - c_start + 1);     // vertices this worker can dequeue
+    if (GC) {
+        g.sh = 1; g.X = (int)NT - 1;
+        g.sh_tab = p.sh_cnt + (uint64_t)t * (2u + 2u * DG_SH_MAX); g.seg = me - wlo;
+        g.lg_cap = p.sh_log; g.lg_cnt = p.seg_done + (uint64_t)me * (DG_SH_MAX + 1u);
+    }
+    const int X = GC ? (int)NT - 1 : -1;                   // exit, where it must be left alone
+    const uint32_t N = own_q ? NT : (uint32_t)(c_hi - c_start + 1);     // vertices this worker can dequeue
     uint32_t qh = 0, qt = 1;
     // (a ring entry carries what the visit needs of its vertex's record when the one who queued the vertex had it at hand
     // -- lens = -1: not so.  The record of a queued vertex does not change before its visit: whoever could touch its lists
     // is one of its predecessors, or has one of them for a predecessor, and those have all been visited)
-    if (lane == 0) { g.queue[0] = c_start; s_ring[0] = make_int4(c_start, -1, 0, 0); }
+    if (own_q) {
+        // the prologue has visited enter (and what hangs on it alone): go on from its queue
+        qh = p.pro_state[4u * t]; qt = p.pro_state[4u * t + 1u];
+        // (the ring holds the youngest DQ_RING entries)
+        for (uint32_t i = (qt - qh > DQ_RING ? qt - DQ_RING : qh) + (uint32_t)lane; i < qt; i += DQ_W) s_ring[i & (DQ_RING - 1)] = make_int4(g.queue[i], -1, 0, 0);
+    } else if (lane == 0) { g.queue[0] = c_start; s_ring[0] = make_int4(c_start, -1, 0, 0); }
     DQ_FENCE();
     // Two phases per round, so that the rows of a wave spend their time on the same code: (A) every row runs
     // through the visits that merge nothing (one look, the FIFO bookkeeping) until it meets a visit that has a merge
@@ -398,7 +418,10 @@ __device__ __forceinline__ void dq_merge_segment(const DgParams &p, const uint32
                     const qmask cand = dq_ballot(valid && ((h.x >> (is_in ? 0u : 16u)) & 0xffffu) == 1u);
                     // a merge group = two candidates of one side with the same base
                     int work = 0;
-                    if (__popc(cand & DQ_LO) >= 2 || __popc(cand & (DQ_ALL & ~DQ_LO)) >= 2) {
+                    // (GC: next to enter / exit / a shared vertex the visit goes the literal way, where their lists are
+                    // handled by the protocol; '^' and '$' are nobody else's base, so none of them is ever a group's member)
+                    if (GC && dq_ballot(valid && ((h.y >> 8) & DG_NF_SHARED))) work = 2;
+                    else if (__popc(cand & DQ_LO) >= 2 || __popc(cand & (DQ_ALL & ~DQ_LO)) >= 2) {
                         const int key = ((cand >> lane) & 1u) ? (DG_H_BASE(h) | (is_in ? 0 : 256)) : -1 - lane;
                         qmask m = cand;
                         while (m) {
@@ -429,6 +452,14 @@ __device__ __forceinline__ void dq_merge_segment(const DgParams &p, const uint32
         if (st != DQ_ST_NEED) break;                       // the queue ran dry, the cut was reached, or something failed
         const bool skip_in = c_start != 0 && u == c_start, in_only = u == c_end;
         bool scalar = false;
+        if (GC) {
+            // is u a neighbour of enter, exit or a shared vertex?  (whatever the lengths of its lists)
+            const uint4 ql = dg_lo16(&DG_NV(g, u)), qhh = dg_hi16(&DG_NV(g, u));
+            bool f = false;
+            if (!skip_in) for (int i = lane; i < DG_H_INLEN(ql); i += DQ_W) f |= ((dg_lo16(&DG_NV(g, (int)DG_PW(g, DG_H2_INOFF(qhh) + i))).y >> 8) & DG_NF_SHARED) != 0;
+            if (!in_only) for (int i = lane; i < DG_H_OUTLEN(ql); i += DQ_W) f |= (int)DG_PW(g, DG_H2_OUTOFF(qhh) + 2 * i) == X;
+            if (dq_ballot(f)) scalar = true;              // the literal path handles their lists
+        }
 
         // ---------------- mergeInNodes(u), recursion on an explicit stack ----------------
         int sp = skip_in ? 0 : 1;
@@ -441,7 +472,7 @@ __device__ __forceinline__ void dq_merge_segment(const DgParams &p, const uint32
             if (valid) s = (int)DG_PW(g, DG_H2_INOFF(nh) + lane);
             uint4 h = make_uint4(0, 0, 0, 0);
             if (valid) h = dg_lo16(&DG_NV(g, s));
-            const qmask cand = dq_ballot(valid && DG_H_OUTLEN(h) == 1);
+            const qmask cand = dq_ballot(valid && DG_H_OUTLEN(h) == 1 && !(GC && ((h.y >> 8) & DG_NF_SHARED)));
             qmask M = 0;
             int b = 256;
             if (__popc(cand) >= 2) b = dq_pick_group(cand, DG_H_BASE(h), fr_last, lane, &M);
@@ -484,7 +515,7 @@ __device__ __forceinline__ void dq_merge_segment(const DgParams &p, const uint32
             uint4 h = make_uint4(0, 0, 0, 0);
             if (valid) h = dg_lo16(&DG_NV(g, d));
             if (!scalar) {
-                const qmask cand = dq_ballot(valid && DG_H_INLEN(h) == 1);
+                const qmask cand = dq_ballot(valid && DG_H_INLEN(h) == 1 && d != X);
                 qmask M = 0;
                 int b = 256;
                 if (__popc(cand) >= 2) b = dq_pick_group(cand, DG_H_BASE(h), last_out, lane, &M);
@@ -500,9 +531,10 @@ __device__ __forceinline__ void dq_merge_segment(const DgParams &p, const uint32
             }
             // AlnGraphBoost.cpp:143-158
             const int pend = DG_H_PEND(h) - 1;
-            if (valid) DG_NV(g, d).pending = pend;
-            const qmask rm = dq_ballot(valid && pend == 0);
-            if (valid && pend == 0) {
+            const bool bk = valid && d != X;              // (the exit vertex is k_merge_fin's)
+            if (bk) DG_NV(g, d).pending = pend;
+            const qmask rm = dq_ballot(bk && pend == 0);
+            if (bk && pend == 0) {
                 const uint32_t pos = qt + (uint32_t)__popc(rm & DQ_LT(lane));
                 if (pos < N) { g.queue[pos] = d; s_ring[pos & (DQ_RING - 1)] = make_int4(d, -1, 0, 0); }
             }
@@ -519,6 +551,7 @@ __device__ __forceinline__ void dq_merge_segment(const DgParams &p, const uint32
                 const int len = gs.nd[u].out_len;
                 for (int i = 0; i < len && !gs.err; i++) {
                     const int v = (int)gs.pool[off + 2 * i];
+                    if (v == X) continue;
                     const int pend = gs.nd[v].pending - 1;
                     gs.nd[v].pending = pend;
                     if (pend == 0) {
@@ -557,5 +590,39 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DQ_WAVES, DQ
     if (seg >= nseg) return;
     const int c_start = (int)crow[1 + seg];
     const int c_end = seg + 1 < nseg ? (int)crow[2 + seg] : 0x7fffffff;
-    dq_merge_segment(p, t, c_start, c_end, p.stk + (uint64_t)pair * p.stk_words, s_stk[row], s_ring[row]);
+    dq_merge_segment<false>(p, t, c_start, c_end, p.stk + (uint64_t)pair * p.stk_words, s_stk[row], s_ring[row]);
 }
+
+#ifdef DG_EXPERIMENTS
+// (make experiments; DAGCON_MERGE_LIST_Q=1.  Exact on the whole suite, and no faster than a wave per entry: config-5 shape,
+// 400 / 1,000 / 2,000 targets: merge 22.0 / 33.0 / 56.4 ms against k_merge_list's 13.4 / 29.1 / 55.7 -- see DESIGN.md)
+// The worklist of k_cuts2 (partial-span pileups; see k_merge_list), eight entries per wave: a wave takes eight consecutive
+// entries by ticket, row r the r-th of them, until the list is done.
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DQ_WAVES, DQ_WAVES))) void k_merge_list_q(DgParams p) {
+    __shared__ int s_stk[DQ_ROWS][2 * DQ_IN_STACK];
+    __shared__ int4 s_ring[DQ_ROWS][DQ_RING];
+    if (dg_failed(p)) return;
+    const uint32_t row = threadIdx.x / DQ_W;
+    const uint32_t n = p.tile_list[0] < p.tile_list_cap ? p.tile_list[0] : p.tile_list_cap;
+    for (;;) {
+        uint32_t i0 = 0;
+        if (threadIdx.x == 0) i0 = atomicAdd(&p.tile_list[2], (uint32_t)DQ_ROWS);
+        i0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)i0);
+        if (i0 >= n) break;
+        const uint32_t i = i0 + row;
+        if (i < n) {
+            const uint32_t t = p.tile_list[4 + 3 * i];
+            const int c_start = (int)p.tile_list[5 + 3 * i];
+            const uint32_t ce = p.tile_list[6 + 3 * i];
+            if (!dg_tskip(p, t)) {
+                dq_merge_segment<true>(p, t, c_start, ce == DG_NOSEG_END ? 0x7fffffff : (int)ce, p.stk + (uint64_t)(blockIdx.x * DQ_ROWS + row) * p.stk_words,
+                                       s_stk[row], s_ring[row], i, p.wl_first[t]);
+                if ((threadIdx.x & (DQ_W - 1)) == 0) atomicAdd(&p.st->n_mseg, 1u);
+            }
+        }
+        DQ_FENCE();
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && p.tile_list[0] > p.tile_list_cap) dg_fail(p, DG_E_LIST_OVF);
+}
+
+#endif
