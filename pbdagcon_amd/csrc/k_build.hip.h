@@ -1023,9 +1023,12 @@ __global__ __launch_bounds__(256) void k_gsum(DgParams p) {
 #define DG_ERPW 64          // reads per wave (16 or 32 were tried: no faster)
 #endif
 #ifndef DG_ECOLS
-#define DG_ECOLS 48u          // columns staged in LDS per lane and batch (6 x 16 bytes)
-#define DG_ECOLS_STRIDE 50u   // 25 dwords per lane row: odd, lanes spread over banks
+#define DG_ECOLS 40u          // columns staged in LDS per lane and batch (5 x 16 bytes)
+#define DG_ECOLS_STRIDE 42u   // 21 dwords per lane row: odd, lanes spread over banks
+#define DG_ENEED 16u          // columns a batch wants staged when it starts (restaged in place if it needs more)
 #endif
+// (LDS, not registers, bounds the waves in flight here: 2 KB of departure cells + the staged columns.  48 / 40 / 32 / 24
+// columns -> 8.4 / 7.4 / 6.4 / 5.4 KB, 86 / 82 / 78 / 74 VGPRs, 5 / 5 / 6 / 6 waves per SIMD: build 10.08 / 9.85 / 9.97 / 10.01 ms)
 __global__ __launch_bounds__(64) void k_emit(DgParams p) {
     __shared__ uint32_t s_D[DG_EB * 64];
     __shared__ uint16_t s_col[64 * DG_ECOLS_STRIDE];
@@ -1183,7 +1186,7 @@ __global__ __launch_bounds__(64) void k_emit(DgParams p) {
                 cmv[j] = __ballot(x != 0u) ? dg_wave_excl(x, lane) : 0u;
             }
         }
-        if (bbpos != DG_EDONE && i < hi && (i - c_base) + 24u > DG_ECOLS) DG_STAGE(i);
+        if (bbpos != DG_EDONE && i < hi && (i - c_base) + DG_ENEED > DG_ECOLS) DG_STAGE(i);
         uint32_t acell[DG_EB];
 #pragma unroll
         for (int j = 0; j < DG_EB; j++) { acell[j] = 0; s_D[j * 64 + lane] = 0; }
