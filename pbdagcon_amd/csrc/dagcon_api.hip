@@ -100,7 +100,7 @@ struct Ctx {
     int emit2 = 0;                                 // addAln with a thread per column (k_emit2.hip.h; DAGCON_EMIT2)
     uint32_t max_len = 0, bs_stride = 0;
     DevBuf d_matK, d_bbstart;
-    int bp_lane = 1, bl_stk = -1;                  // full-span bestPath: a lane per piece (k_bp_sweep_l; DAGCON_BP_LANE=0: a wave per piece, k_bp_sweep); DAGCON_BP_LANE_STACK: test knob
+    int bp_lane = 1, bl_stk = -1;                  // full-span bestPath: a row of eight lanes per piece (k_bp_sweep_l; DAGCON_BP_LANE=0: a wave per piece, k_bp_sweep; 2: rows whatever the batch size); DAGCON_BP_LANE_STACK: test knob
     int bp_fused = 1;                              // partial-span bestPath: one (A, B) sweep + vertex-parallel kernels (DAGCON_BP_FUSED=0: three sweeps)
     uint32_t align_dropped = 0;                    // records of the last dagcon_align / dagcon_consensus_pre the band could not align
     int emit_scan = 1;                             // k_emit takes the prefix over the reads itself (DAGCON_EMIT_SCAN=0: k_groups, as for deeper targets)
@@ -310,7 +310,9 @@ void fill_params(Ctx *c, DgParams &p) {
 #endif
     p.emit2 = c->emit2 ? 1u : 0u; p.matK = (uint8_t *)c->d_matK.p; p.bbstart = (uint32_t *)c->d_bbstart.p; p.bs_stride = c->bs_stride;
     p.bp_fused = c->bp_fused ? 1u : 0u; p.score_b = (float *)c->d_score_b.p;
-    p.bp_lane = c->bp_lane ? 1u : 0u; p.bl_stk = c->bl_stk >= 0 && c->bl_stk < DG_BL_STK ? (uint32_t)c->bl_stk : (uint32_t)DG_BL_STK;
+    // (rows pay where there are pieces enough to fill the chip with them, eight to a wave: 64 targets x 50 kb x 60x, 16,384
+    // pieces: 2.9 ms by rows against 2.3 by waves; configs[1], 147,000 pieces: 3.8 against 4.7.  DAGCON_BP_LANE=2: always)
+    p.bp_lane = c->bp_lane >= 2 || (c->bp_lane && (uint64_t)c->T * c->bp_max >= 32768ull) ? 1u : 0u; p.bl_stk = c->bl_stk >= 0 && c->bl_stk < DG_BL_STK ? (uint32_t)c->bl_stk : (uint32_t)DG_BL_STK;
     p.emit_scan = (c->emit_scan && c->max_k <= 64u && !c->emit2) ? 1u : 0u;
     p.fold = (c->fold && !(c->opts.flags & DAGCON_FLAG_STOP_AFTER_BUILD)) ? 1u : 0u;
     p.q_kmax = c->use_q && !c->opts.max_segments && !c->seg_env && c->max_k > DQ_KMAX ? DQ_KMAX : 0u;
@@ -504,7 +506,7 @@ int dagcon_create(const dagcon_opts *opts, dagcon_ctx **out) {
     if (const char *e = getenv("DAGCON_NF2")) c->nf2 = atoi(e) != 0;
     if (const char *e = getenv("DAGCON_EMIT_SCAN")) c->emit_scan = atoi(e) != 0;
     if (const char *e = getenv("DAGCON_BP_FUSED")) c->bp_fused = atoi(e) != 0;
-    if (const char *e = getenv("DAGCON_BP_LANE")) c->bp_lane = atoi(e) != 0;
+    if (const char *e = getenv("DAGCON_BP_LANE")) c->bp_lane = atoi(e);
     if (const char *e = getenv("DAGCON_BP_LANE_STACK")) c->bl_stk = atoi(e);
 #ifdef DG_EXPERIMENTS
     if (const char *e = getenv("DAGCON_EMIT2")) c->emit2 = atoi(e) != 0;

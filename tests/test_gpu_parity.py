@@ -1199,6 +1199,8 @@ def test_round3_paths_and_their_checkers_agree(knob, monkeypatch):
     batches.append((batch_from_targets(targets), dict(min_cov=0, min_len=0, trim=0, min_weight=0)))
     for val in ("0", "1"):
         monkeypatch.setenv(knob, val)
+        if knob == "DAGCON_BP_LANE" and val == "1": monkeypatch.setenv(knob, "2")     # (2: whatever the batch size)
+        if knob == "DAGCON_BP_LANE_STACK": monkeypatch.setenv("DAGCON_BP_LANE", "2")
         for b, kw in batches:
             exp = oracle_batch(b, kw["min_cov"], kw["min_len"], kw["trim"], kw.get("min_weight"))
             ctx = capi.Context(**kw)
