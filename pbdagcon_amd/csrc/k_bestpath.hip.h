@@ -569,13 +569,24 @@ __global__ __launch_bounds__(64) void k_bp_sweep_l(DgParams p) {
     const uint32_t guard_max = 64u * (uint32_t)(v_top - c_bot + 1) + 1000000u;
     // What a step needs of its vertex x -- out_len | in_len, base | flags, out_off, the final flag of its score, its own
     // target term -- is five words at three places: lanes 0 .. 4 of the row fetch one each (one load instruction), and the
-    // row reads them off those lanes.
+    // row reads them off those lanes.  Lanes 5 .. 7 fetch the flags of x - 1, x - 2, x - 3 with them: a third of the ids are
+    // vertices the merge deleted, and the stream steps over those it knows of (DBR_BELOW).
 #define DBR_GATHER(X, OUT)                                                                               \
     do {                                                                                                 \
-        const char *a_ = reinterpret_cast<const char *>(&nd[X]) + (l == 1 ? 4 : l == 2 ? 16 : 0);       \
-        if (l == 3) a_ = reinterpret_cast<const char *>(&score[X]) + 4;                                  \
-        if (l == 4) a_ = reinterpret_cast<const char *>(&tt[X]);                                         \
+        int xl_ = (X);                                                                                   \
+        if (l >= 5) { xl_ -= l - 4; if (xl_ < 0) xl_ = 0; }                                              \
+        const char *a_ = reinterpret_cast<const char *>(&nd[xl_]) + ((l == 1 || l >= 5) ? 4 : l == 2 ? 16 : 0); \
+        if (l == 3) a_ = reinterpret_cast<const char *>(&score[xl_]) + 4;                                \
+        if (l == 4) a_ = reinterpret_cast<const char *>(&tt[xl_]);                                       \
         OUT = *reinterpret_cast<const uint32_t *>(a_);                                                   \
+    } while (0)
+    // the stream's vertex behind X, G = X's gathered words: the first of X - 1, X - 2, X - 3 that is not deleted, else X - 4
+    // (-1: the piece ends first; its lowest vertex is a cut vertex, which nobody deletes)
+#define DBR_BELOW(G, X, OUT)                                                                             \
+    do {                                                                                                 \
+        const uint32_t dm_ = dbr_ballot(l >= 5 && (((G) >> 8) & DG_NF_DELETED));                          \
+        const int nx_ = (X) - (!(dm_ & 32u) ? 1 : !(dm_ & 64u) ? 2 : !(dm_ & 128u) ? 3 : 4);              \
+        OUT = nx_ >= c_bot ? nx_ : -1;                                                                   \
     } while (0)
 #define DBR_DECODE(G, LOX, LOY, OFF, FIN, TTN)                                                           \
     do {                                                                                                 \
@@ -601,13 +612,14 @@ __global__ __launch_bounds__(64) void k_bp_sweep_l(DgParams p) {
     // are on their way (c_*: record and edges of vertex cv, the next one of the stream; raw: the words of cv - 1).
     int v = v_top, n = v_top, sp = 0;
     int going = v_top >= c_bot ? 1 : 0;
-    int cv = -1, c_d = 0, c_cnt = 0;
+    int cv = -1, rv = -1, c_d = 0, c_cnt = 0;          // cv: the vertex whose record and edges c_* hold; rv: the one whose words raw holds
     uint32_t c_lox = 0, c_loy = 0, c_off = 0, raw = 0;
     float c_fin = 0.0f, c_ttn = 0.0f;
     if (going) {
         uint32_t g0;
         DBR_GATHER(v_top, g0);
-        if (v_top > c_bot) DBR_GATHER(v_top - 1, raw);
+        DBR_BELOW(g0, v_top, rv);
+        if (rv >= 0) DBR_GATHER(rv, raw);
         DBR_DECODE(g0, c_lox, c_loy, c_off, c_fin, c_ttn);
         DBR_EDGES(c_lox, c_loy, c_off, c_d, c_cnt);
         cv = v_top;
@@ -624,11 +636,12 @@ __global__ __launch_bounds__(64) void k_bp_sweep_l(DgParams p) {
             // (copied here and now: the loads below then land in the c_* registers themselves, and nobody has to wait for
             // them before the next step)
             asm volatile("" : "+v"(lox), "+v"(loy), "+v"(out_off), "+v"(fin), "+v"(ttn), "+v"(d), "+v"(cnt));
-            if (cv > c_bot) {
+            if (rv >= 0) {
                 DBR_DECODE(raw, c_lox, c_loy, c_off, c_fin, c_ttn);
                 DBR_EDGES(c_lox, c_loy, c_off, c_d, c_cnt);
-                cv--;
-                if (cv > c_bot) DBR_GATHER(cv - 1, raw);
+                cv = rv;
+                DBR_BELOW(raw, cv, rv);
+                if (rv >= 0) DBR_GATHER(rv, raw);
             } else cv = -1;
         } else {
             // a vertex off the stack (or the stream's vertex once more, behind one): fetched now
@@ -696,11 +709,12 @@ __global__ __launch_bounds__(64) void k_bp_sweep_l(DgParams p) {
         }
         if (next) {
             if (sp > 0) { sp--; n = stk[sp]; }
-            else { v--; n = v; if (v < c_bot) going = 0; }
+            else { v = cv; n = v; if (v < 0) going = 0; }     // (the stream's next vertex is the one the pipeline holds)
         }
     }
     DBR_FLUSH();
 #undef DBR_GATHER
+#undef DBR_BELOW
 #undef DBR_DECODE
 #undef DBR_EDGES
 #undef DBR_FLUSH
