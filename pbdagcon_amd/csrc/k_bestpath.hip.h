@@ -571,14 +571,16 @@ __global__ __launch_bounds__(64) void k_bp_sweep_l(DgParams p) {
     // target term -- is five words at three places: lanes 0 .. 4 of the row fetch one each (one load instruction), and the
     // row reads them off those lanes.  Lanes 5 .. 7 fetch the flags of x - 1, x - 2, x - 3 with them: a third of the ids are
     // vertices the merge deleted, and the stream steps over those it knows of (DBR_BELOW).
+    // (a lane's word of vertex x sits at g_base + (x - g_back) << g_shift: the three places differ in base and stride only)
+    const char *g_base = reinterpret_cast<const char *>(nd) + ((l == 1 || l >= 5) ? 4 : l == 2 ? 16 : 0);
+    uint32_t g_shift = 5;
+    if (l == 3) { g_base = reinterpret_cast<const char *>(score) + 4; g_shift = 3; }
+    if (l == 4) { g_base = reinterpret_cast<const char *>(tt); g_shift = 2; }
+    const int g_back = l >= 5 ? l - 4 : 0;
 #define DBR_GATHER(X, OUT)                                                                               \
     do {                                                                                                 \
-        int xl_ = (X);                                                                                   \
-        if (l >= 5) { xl_ -= l - 4; if (xl_ < 0) xl_ = 0; }                                              \
-        const char *a_ = reinterpret_cast<const char *>(&nd[xl_]) + ((l == 1 || l >= 5) ? 4 : l == 2 ? 16 : 0); \
-        if (l == 3) a_ = reinterpret_cast<const char *>(&score[xl_]) + 4;                                \
-        if (l == 4) a_ = reinterpret_cast<const char *>(&tt[xl_]);                                       \
-        OUT = *reinterpret_cast<const uint32_t *>(a_);                                                   \
+        const int xl_ = (X) - g_back;                                                                    \
+        OUT = *reinterpret_cast<const uint32_t *>(g_base + ((uint64_t)(uint32_t)(xl_ < 0 ? 0 : xl_) << g_shift)); \
     } while (0)
     // the stream's vertex behind X, G = X's gathered words: the first of X - 1, X - 2, X - 3 that is not deleted, else X - 4
     // (-1: the piece ends first; its lowest vertex is a cut vertex, which nobody deletes)
