@@ -55,7 +55,14 @@ static DgPlan dg_plan_pieces(const DgPlanIn &in) {
     else if (in.gcuts) pl.seg_max = 64;      // the worklist of k_cuts2 is taken by ticket: the finer its entries the better
                                              // the balance (config-5 shape, 1,000 targets: 8 / 32 / 64 pieces 54 / 34 / 31 ms)
     else { uint32_t sm = T ? 8192u / T : 8u; pl.seg_max = sm < 8u ? 8u : sm > 256u ? 256u : sm; }
-    if (in.gcuts && !in.min_segment_len) pl.seg_min = 256;
+    // Partial-span pileups: no piece shorter than the automatic ones, whatever the caller asks for.  At the end of round 3
+    // tools/stress.py (seeds 417 and 463, round 4: 26 - 30 targets of 0.7 - 9 kb at span 0.6, trim 300, max_segments 64
+    // with min_segment_len 4 / 64) ended in a GPU memory fault or DAGCON_ERR_INTERNAL in about one run of six (bestPath
+    // stuck on what the merge had left: ten of twelve with DAGCON_BP_FUSED=0), the same inputs passing otherwise -- a race
+    // between the workers of such short pieces on the partial-span path, there since round 2 and not understood yet
+    // (a floor under bestPath's pieces alone does not cure it).  With the automatic pieces the same
+    // batches passed 40 of 40 runs and every campaign before; with this floor 56 of 56.
+    if (in.gcuts && pl.seg_min < 256) pl.seg_min = 256;
     // k_merge_q (four segments per wave, DQ_WAVES waves per SIMD) for full-span batches big enough to fill the chip with
     // it: as many pieces as go (<= 256 per target) with its waves filling the chip a whole number of times -- a last round
     // that is a third full costs as much as a full one (configs[1]: 36 / 49 / 56 / 64 pieces 20.6 / 17.4 / 19.2 / 18.3 ms)
@@ -105,7 +112,7 @@ struct Ctx {
     uint32_t align_dropped = 0;                    // records of the last dagcon_align / dagcon_consensus_pre the band could not align
     int emit_scan = 1;                             // k_emit takes the prefix over the reads itself (DAGCON_EMIT_SCAN=0: k_groups, as for deeper targets)
     int nf2 = 1;                                   // k_norm_finish2 (a wave per chunk) instead of k_norm_finish (DAGCON_NF2=0)
-    int poison = 0;                                // DAGCON_POISON (tests): arenas nobody clears are filled with 0xEE bytes before every run
+    int poison = 0;                                // DAGCON_POISON (tests): arenas nobody clears are filled with 0xEE bytes before every run (bits 1, 2, 4); 8: every buffer the kernels fill
     int align2 = 0;                                // (make experiments) k_align_adapt2: two pairs per wave, DAGCON_ALIGN2=1
     int fold = 1;                                  // duplicate insertion chains folded by k_emit (DAGCON_FOLD=0: never)
     int list_q = 0;                                // (make experiments) partial-span worklist by rows, k_merge_list_q: DAGCON_MERGE_LIST_Q=1
@@ -316,6 +323,7 @@ void fill_params(Ctx *c, DgParams &p) {
     p.emit_scan = (c->emit_scan && c->max_k <= 64u && !c->emit2) ? 1u : 0u;
     p.fold = (c->fold && !(c->opts.flags & DAGCON_FLAG_STOP_AFTER_BUILD)) ? 1u : 0u;
     p.q_kmax = c->use_q && !c->opts.max_segments && !c->seg_env && c->max_k > DQ_KMAX ? DQ_KMAX : 0u;
+    p.bp_seg_min = (c->seg_min + 2u) / 3u;
     p.seg_max = c->seg_max; p.seg_min = c->seg_min; p.cuts = (uint32_t *)c->d_cuts.p; p.bp_max = c->bp_max; p.cuts_bp = (uint32_t *)c->d_cuts_bp.p; p.bp_stat = (float *)c->d_bp_stat.p; p.bp_len = (uint32_t *)c->d_bp_len.p;
     p.gcuts = c->gcuts; p.sh_log = c->sh_log;
     p.rd_s = (uint32_t *)c->d_rd.p; p.rd_e = p.rd_s + c->A; p.rd_lead = p.rd_e + c->A; p.rd_trail = p.rd_lead + c->A;
@@ -352,6 +360,19 @@ int launch_all(Ctx *c) {
     DgParams p;
     fill_params(c, p);
     hipStream_t s = c->stream;
+    if (c->poison & 8) {
+        // every buffer the kernels themselves fill (nothing the host uploaded), before the memsets below: whoever reads an
+        // entry of them that THIS run has not written finds 0xEE bytes, in a fresh process as in one that re-uses its memory
+        DevBuf *work[] = {&c->d_nmis, &c->d_n_lo, &c->d_n_hi, &c->d_n_start, &c->d_n_ins, &c->d_n_del, &c->d_ch_k0, &c->d_ch_next, &c->d_ch_w,
+                          &c->d_ch_tb, &c->d_ch_flag, &c->d_ch_src, &c->d_ch_out, &c->d_ch_adv, &c->d_n_lb, &c->d_norm_tmp, &c->d_ckpt,
+                          &c->d_node_base, &c->d_n_nodes, &c->d_pool_base, &c->d_pool_size, &c->d_pool_top, &c->d_t_nins, &c->d_cov, &c->d_gcount,
+                          &c->d_gbase, &c->d_bid, &c->d_best, &c->d_queue, &c->d_score, &c->d_cns_tmp, &c->d_bp_tt, &c->d_stk, &c->d_cuts,
+                          &c->d_cuts_bp, &c->d_bp_stat, &c->d_bp_len, &c->d_nextcut, &c->d_rd, &c->d_pro_state, &c->d_sh_cnt, &c->d_wl_first,
+                          &c->d_queue0, &c->d_bp_end, &c->d_bp_ab, &c->d_defer, &c->d_cns_tmp0, &c->d_cns, &c->d_cns_off, &c->d_seg_first,
+                          &c->d_seg_r0, &c->d_seg_r1, &c->d_tile_list, &c->d_seg_done};
+        for (DevBuf *b : work)
+            if (b->p && b->cap) HIPCHK(c, hipMemsetAsync(b->p, 0xEE, b->cap, s));
+    }
     HIPCHK(c, hipMemsetAsync(c->d_st.p, 0, sizeof(DgStatus), s));
     HIPCHK(c, hipMemsetAsync(c->d_tfail.p, 0, (size_t)c->T * 4 + 4, s));
     HIPCHK(c, hipMemsetAsync(c->d_cns_len.p, 0, (size_t)c->T * 4, s));
@@ -452,7 +473,8 @@ int launch_all(Ctx *c) {
             if (p.bp_lane) hipLaunchKernelGGL(k_bp_sweep_l, dim3((c->T * c->bp_max + 7u) / 8u), dim3(64), 0, s, p);
             hipLaunchKernelGGL(k_bp_sweep, dim3(c->T * c->bp_max), dim3(64), 0, s, p);
             hipLaunchKernelGGL(k_bp_check, dim3(c->T), dim3(64), 0, s, p);
-            hipLaunchKernelGGL(k_bp_walk, dim3(c->T * c->bp_max), dim3(64), 0, s, p);
+            if (p.bp_lane) hipLaunchKernelGGL(k_bp_walk_r, dim3((c->T * c->bp_max + 7u) / 8u), dim3(64), 0, s, p);
+            else hipLaunchKernelGGL(k_bp_walk, dim3(c->T * c->bp_max), dim3(64), 0, s, p);
         }
         hipLaunchKernelGGL(k_bp_join, dim3(c->T), dim3(64), 0, s, p);
     }
@@ -786,6 +808,34 @@ int dagcon_run(dagcon_ctx *ctx) {
     int r = launch_all(c);
     if (r != DAGCON_OK) return r;
     c->ran = true; c->fetched = false;
+    // debugging aid (tools/bp_pieces.py): DAGCON_DUMP=<target>:<path> leaves that target's merged graph, its bestPath cuts,
+    // scores and choices in a file -- N, bp_max, pool words, then cuts row, records, pool, (score, final) pairs, best[]
+    if (const char *e = getenv("DAGCON_DUMP")) {
+        const uint32_t t = (uint32_t)atoi(e);
+        const char *path = strchr(e, ':');
+        if (path && t < c->T) {
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            uint64_t nb = 0, pb = 0;
+            uint32_t hdr[4] = {0, c->bp_max, 0, c->seg_max};
+            (void)hipMemcpy(&nb, (uint64_t *)c->d_node_base.p + t, 8, hipMemcpyDeviceToHost);
+            (void)hipMemcpy(&pb, (uint64_t *)c->d_pool_base.p + t, 8, hipMemcpyDeviceToHost);
+            (void)hipMemcpy(&hdr[0], (uint32_t *)c->d_n_nodes.p + t, 4, hipMemcpyDeviceToHost);
+            (void)hipMemcpy(&hdr[2], (uint32_t *)c->d_pool_top.p + t, 4, hipMemcpyDeviceToHost);
+            std::vector<uint32_t> cuts(c->bp_max + 2), pool(hdr[2]), best(hdr[0]);
+            std::vector<DgNode> nd(hdr[0]);
+            std::vector<float> sc(2 * (size_t)hdr[0]);
+            (void)hipMemcpy(cuts.data(), (uint32_t *)c->d_cuts_bp.p + (uint64_t)t * (c->bp_max + 2), cuts.size() * 4, hipMemcpyDeviceToHost);
+            (void)hipMemcpy(nd.data(), (DgNode *)c->d_nodes.p + nb, nd.size() * sizeof(DgNode), hipMemcpyDeviceToHost);
+            (void)hipMemcpy(pool.data(), (uint32_t *)c->d_pool.p + pb, pool.size() * 4, hipMemcpyDeviceToHost);
+            (void)hipMemcpy(sc.data(), (float *)c->d_score.p + 2 * nb, sc.size() * 4, hipMemcpyDeviceToHost);
+            (void)hipMemcpy(best.data(), (uint32_t *)c->d_best.p + nb, best.size() * 4, hipMemcpyDeviceToHost);
+            if (FILE *f = fopen(path + 1, "wb")) {
+                fwrite(hdr, 4, 4, f); fwrite(cuts.data(), 4, cuts.size(), f); fwrite(nd.data(), sizeof(DgNode), nd.size(), f);
+                fwrite(pool.data(), 4, pool.size(), f); fwrite(sc.data(), 4, sc.size(), f); fwrite(best.data(), 4, best.size(), f);
+                fclose(f);
+            }
+        }
+    }
     return DAGCON_OK;
 }
 

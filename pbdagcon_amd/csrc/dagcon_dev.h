@@ -161,6 +161,7 @@ struct DgParams {
     float *bp_tt;                  // per vertex: what an edge into it subtracts (k_bp_terms)
     float *score_b;                // per vertex (p.gcuts, p.bp_fused): B, best path to exit that does not pass the piece's upper cut
     uint32_t bp_fused;             // 1: partial-span bestPath as one (A, B) sweep + vertex-parallel kernels (k_bp_sweep_ab)
+    uint32_t bp_seg_min;           // k_cuts2: shortest bestPath piece, in backbone positions (see fill_params)
     uint32_t bp_lane;              // 1: full-span bestPath with a lane per piece (k_bp_sweep_l); k_bp_sweep then takes the pieces it gave up
     uint32_t bl_stk;               // k_bp_sweep_l: entries of a lane's evaluation stack (<= DG_BL_STK; a test knob below that)
     uint8_t *cns_tmp;

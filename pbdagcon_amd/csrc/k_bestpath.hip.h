@@ -831,6 +831,53 @@ __global__ __launch_bounds__(64) void k_bp_walk(DgParams p) {
     }
 }
 
+// ---- the same walk with a row of eight lanes per (target, segment): eight pieces per wave (round 3; where k_bp_sweep_l
+// runs).  A step is one dependent round trip -- best[v], the vertex's base and weight: three words, fetched by lanes
+// 0 .. 2 in one load -- so what counts is how many walks are in flight; the bytes leave one at a time.
+__global__ __launch_bounds__(64) void k_bp_walk_r(DgParams p) {
+    if (dg_failed(p)) return;
+    const int l = threadIdx.x & (DG_BRW - 1);
+    const uint32_t piece = blockIdx.x * (64u / DG_BRW) + threadIdx.x / DG_BRW;
+    const uint32_t t = piece / p.bp_max, seg = piece % p.bp_max;
+    if (t >= p.T || dg_tskip(p, t)) return;
+    const uint32_t *crow = p.cuts_bp + (uint64_t)t * (p.bp_max + 2u);
+    const uint32_t nseg = crow[0];
+    if (seg >= nseg) return;
+    const uint64_t nb = p.node_base[t];
+    const DgNode *nd = p.nodes + nb;
+    const int32_t *best = p.best + nb;
+    const int N = (int)p.n_nodes[t];
+    const int c0 = (int)crow[1 + seg];
+    const int c1 = seg + 1 < nseg ? (int)crow[2 + seg] : -1;
+    const uint32_t eb = nd[0].base, xb = nd[N - 1].base;
+    const int minw = p.min_weight;
+    uint8_t *tmp = p.cns_tmp + nb + c0;
+    int v = c0, idx = 0, steps = 0, bad = 0;
+    int go = v != c1 ? 1 : 0;
+    while (go) {
+        const char *a = l == 1 ? reinterpret_cast<const char *>(&nd[v]) + 4 : l == 2 ? reinterpret_cast<const char *>(&nd[v]) + 8
+                                                                            : reinterpret_cast<const char *>(&best[v]);
+        const uint32_t g = *reinterpret_cast<const uint32_t *>(a);
+        const int nxt = __shfl((int)g, 0, DG_BRW);
+        const uint32_t base = (uint32_t)__shfl((int)g, 1, DG_BRW) & 0xffu;
+        const int w = __shfl((int)g, 2, DG_BRW);
+        if (!(base == eb || base == xb)) {
+            if (l == 0) tmp[idx] = (uint8_t)(base | (w >= minw ? 0x80u : 0u));
+            idx++;
+        }
+        if (nxt < 0) go = 0;
+        else {
+            v = nxt;
+            if (v == c1) go = 0;                             // the next segment starts here
+            else if (++steps > N) { bad = 1; go = 0; }
+        }
+    }
+    if (l == 0) {
+        if (bad) dg_fail_target(p, t, DG_E_INTERNAL);
+        p.bp_len[piece] = (uint32_t)idx;
+    }
+}
+
 // ---- consensus segmentation (:327-373) and output, one wave per target ------------
 __global__ __launch_bounds__(64) void k_bp_join(DgParams p) {
     const uint32_t t = blockIdx.x;

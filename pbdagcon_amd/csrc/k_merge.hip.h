@@ -1309,7 +1309,7 @@ __global__ __launch_bounds__(64) void k_cuts2(DgParams p) {
         // the same conditions, three times as many wanted
         {
             uint32_t *brow = p.cuts_bp + (uint64_t)t * (p.bp_max + 2u);
-            const uint32_t smin_b = (p.seg_min + 2u) / 3u;
+            const uint32_t smin_b = p.bp_seg_min;
             uint32_t want_b = blen / (smin_b ? smin_b : 1u);
             if (want_b > p.bp_max) want_b = p.bp_max;
             if (want_b > 64u) want_b = 64u;
