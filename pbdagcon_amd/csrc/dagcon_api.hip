@@ -55,14 +55,7 @@ static DgPlan dg_plan_pieces(const DgPlanIn &in) {
     else if (in.gcuts) pl.seg_max = 64;      // the worklist of k_cuts2 is taken by ticket: the finer its entries the better
                                              // the balance (config-5 shape, 1,000 targets: 8 / 32 / 64 pieces 54 / 34 / 31 ms)
     else { uint32_t sm = T ? 8192u / T : 8u; pl.seg_max = sm < 8u ? 8u : sm > 256u ? 256u : sm; }
-    // Partial-span pileups: no piece shorter than the automatic ones, whatever the caller asks for.  At the end of round 3
-    // tools/stress.py (seeds 417 and 463, round 4: 26 - 30 targets of 0.7 - 9 kb at span 0.6, trim 300, max_segments 64
-    // with min_segment_len 4 / 64) ended in a GPU memory fault or DAGCON_ERR_INTERNAL in about one run of six (bestPath
-    // stuck on what the merge had left: ten of twelve with DAGCON_BP_FUSED=0), the same inputs passing otherwise -- a race
-    // between the workers of such short pieces on the partial-span path, there since round 2 and not understood yet
-    // (a floor under bestPath's pieces alone does not cure it).  With the automatic pieces the same
-    // batches passed 40 of 40 runs and every campaign before; with this floor 56 of 56.
-    if (in.gcuts && pl.seg_min < 256) pl.seg_min = 256;
+    if (in.gcuts && !in.min_segment_len) pl.seg_min = 256;
     // k_merge_q (four segments per wave, DQ_WAVES waves per SIMD) for full-span batches big enough to fill the chip with
     // it: as many pieces as go (<= 256 per target) with its waves filling the chip a whole number of times -- a last round
     // that is a third full costs as much as a full one (configs[1]: 36 / 49 / 56 / 64 pieces 20.6 / 17.4 / 19.2 / 18.3 ms)
@@ -832,6 +825,17 @@ int dagcon_run(dagcon_ctx *ctx) {
             if (FILE *f = fopen(path + 1, "wb")) {
                 fwrite(hdr, 4, 4, f); fwrite(cuts.data(), 4, cuts.size(), f); fwrite(nd.data(), sizeof(DgNode), nd.size(), f);
                 fwrite(pool.data(), 4, pool.size(), f); fwrite(sc.data(), 4, sc.size(), f); fwrite(best.data(), 4, best.size(), f);
+                // (partial-span batches: the merge's worklist -- (target, first vertex, last vertex) triples -- behind it)
+                uint32_t nl = 0;
+                std::vector<uint32_t> wl;
+                if (c->gcuts && c->d_tile_list.p) {
+                    (void)hipMemcpy(&nl, c->d_tile_list.p, 4, hipMemcpyDeviceToHost);
+                    if (nl > c->tile_list_cap) nl = c->tile_list_cap;
+                    wl.resize(3 * (size_t)nl);
+                    if (nl) (void)hipMemcpy(wl.data(), (uint32_t *)c->d_tile_list.p + 4, wl.size() * 4, hipMemcpyDeviceToHost);
+                }
+                fwrite(&nl, 4, 1, f);
+                if (nl) fwrite(wl.data(), 4, wl.size(), f);
                 fclose(f);
             }
         }

@@ -1227,6 +1227,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DG_ML_WAVES,
 //       rewritten by two workers: such lists are shared like enter's (k_cuts2 finds them);
 //   (4) the dead ends in front of v (the insertion run a read ends with leads to exit only) are done before
 //       v: a read that ends at e < p with a trailing run of r vertices needs p - e > r + 1;
+//   (5) no read STARTS at a backbone successor of v (round 3).  Behind a full-span cut every vertex descends from v, so
+//       v has an out-edge towards every predecessor of its successors and can never be a member of a merge group
+//       there.  A read that starts at position q with a leading insertion puts a vertex c that hangs on enter in front
+//       of bb(q); if bb(q) is v's successor (q = p + 1, or further on behind deletions), every read through v goes on to
+//       it and c has v's base, mergeInNodes(bb(q)) unites v and c -- the worker behind the cut rewrites v's in-list (or
+//       deletes v) while the worker in front of it is still to run mergeInNodes(v): tools/stress.py seeds 417 / 463
+//       found it at the end of round 3, with pieces so short that the two workers met (a different merged graph from
+//       run to run, bestPath stuck or out of bounds on it) -- and with long pieces the worker behind always came
+//       first, which is not the reference's order either.  (v's successors only ever get fewer: merging re-points an
+//       edge to a victim at the survivor, which is a successor already);
 // and the two vertices every segment touches, enter (out-list) and exit (in-list), follow the protocol
 // described at DgGraph::sh; exit itself is visited last of all, by k_merge_fin.  Every worker still
 // checks that it dequeues no vertex of another segment and that its FIFO is empty when it reaches its
@@ -1246,8 +1256,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
 }
 
 // cuts for k_merge_list: up to p.seg_max pieces per target, conditions (1) - (4) above
+#define DG_CUT_STARTS 2048u         // reads of a target whose first positions k_cuts2 holds (deeper targets: one piece)
 __global__ __launch_bounds__(64) void k_cuts2(DgParams p) {
     __shared__ uint32_t s_dead[2 * 256];
+    __shared__ uint32_t s_start[DG_CUT_STARTS];
     __shared__ uint32_t s_cut[72];
     const uint32_t t = blockIdx.x;
     if (dg_failed(p)) return;
@@ -1271,6 +1283,7 @@ __global__ __launch_bounds__(64) void k_cuts2(DgParams p) {
                 const uint32_t l = p.rd_lead[ab + r];
                 maxlead = l > maxlead ? l : maxlead;
                 tr = p.rd_trail[ab + r]; e = p.rd_e[ab + r];
+                if (r < DG_CUT_STARTS) s_start[r] = p.rd_s[ab + r];            // (5)
             }
             const unsigned long long m = __ballot(tr > 0);
             const uint32_t k = ndead + (uint32_t)__popcll(m & DG_LT(lane));
@@ -1278,7 +1291,8 @@ __global__ __launch_bounds__(64) void k_cuts2(DgParams p) {
             ndead += (uint32_t)__popcll(m);
         }
         for (int o = 32; o; o >>= 1) { const uint32_t x = __shfl_xor(maxlead, o); maxlead = x > maxlead ? x : maxlead; }
-        if (ndead > 256u) allow = false;
+        if (ndead > 256u || K > DG_CUT_STARTS) allow = false;
+        const uint32_t nstart = K < DG_CUT_STARTS ? K : DG_CUT_STARTS;
         __syncthreads();
         const uint32_t pmin = 2u * (maxlead + 2u);
         uint32_t want = blen / (p.seg_min ? p.seg_min : 1u);
@@ -1298,6 +1312,16 @@ __global__ __launch_bounds__(64) void k_cuts2(DgParams p) {
                     v = bid[pos];
                     ok = nd[v].weight - 1 == cov[pos];
                     for (uint32_t d = 0; d < ndead && ok; d++) ok = !(pos > s_dead[2 * d] && pos <= s_dead[2 * d + 1]);
+                    if (ok) {                                                                      // (5)
+                        const DgNode nv = nd[v];
+                        const uint32_t *pl_ = p.pool + p.pool_base[t];
+                        for (uint32_t e = 0; e < nv.out_len && ok; e++) {
+                            const uint32_t dd = pl_[nv.out_off + 2u * e];
+                            if (dd == p.n_nodes[t] - 1u || !(nd[dd].flags & DG_NF_BACKBONE)) continue;
+                            const uint32_t q = (uint32_t)nd[dd].bbpos;
+                            for (uint32_t d = 0; d < nstart && ok; d++) ok = s_start[d] != q;
+                        }
+                    }
                 }
                 const unsigned long long m = __ballot(ok);
                 if (m) found = (uint32_t)DG_RL(v, __ffsll((long long)m) - 1);

@@ -104,13 +104,11 @@ def test_piece_plan_never_gives_an_empty_grid():
     # the shape the advice named: 24577 targets below 256 positions each -> not the row kernel with 0 pieces
     lib.dagcon_debug_plan(24577, 24577 * 8, 24577 * 132, 0, 0, 0, out)
     assert out[0] >= 1 and out[3] >= 1
-    # partial-span batches never get pieces shorter than the automatic ones, whatever the caller asks for (the race of
-    # tools/stress.py seeds 417 / 463: tests/test_gpu_parity.py::test_short_pieces_are_not_taken_on_partial_spans)
-    for msl in (0, 4, 64, 255):
-        lib.dagcon_debug_plan(30, 510, 30 * 5000, 1, 64, msl, out)
-        assert out[1] == 256, (msl, list(out))
-    lib.dagcon_debug_plan(30, 510, 30 * 5000, 0, 64, 4, out)
-    assert out[1] == 4, list(out)
+    # the caller's piece length is taken as given, partial spans or not (a floor of 256 stood here for two hours at the end
+    # of round 3, until the race it fenced off was understood: k_cuts2's condition (5))
+    for partial in (0, 1):
+        lib.dagcon_debug_plan(30, 510, 30 * 5000, partial, 64, 4, out)
+        assert out[1] == 4, list(out)
     # configs[1]: 1,000 x 10 kb x 40x keeps the choice the round-2 measurements were made with
     lib.dagcon_debug_plan(1000, 40000, 1000 * 10004, 0, 0, 0, out)
     assert list(out) == [49, 128, 1, 64]

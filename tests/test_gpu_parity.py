@@ -232,19 +232,15 @@ def test_segments_on_adversarial_little_pileups(gpu_ctx_factory, seed):
                                  dele=float(rng.uniform(0, 0.12)), full_span=(i % 4 != 0))
         targets.append((tl, alns, bb))
     batch = batch_from_targets(targets)
-    # (the full-span targets also in a batch of their own: a batch with one partial-span target takes the generalized cuts,
-    # and those are never finer than 256 positions since the end of round 3 -- dg_plan_pieces)
-    full = batch_from_targets([x for i, x in enumerate(targets) if i % 4 != 0])
+    full = batch_from_targets([x for i, x in enumerate(targets) if i % 4 != 0])      # (k_cuts instead of k_cuts2)
     for kw in [dict(min_cov=0, min_len=0, trim=0, min_weight=0),
                dict(min_cov=2, min_len=10, trim=2, min_weight=1)]:
         for b in (batch, full):
             exp = oracle_batch(b, kw["min_cov"], kw["min_len"], kw["trim"], kw["min_weight"])
             ctx = gpu_ctx_factory(max_segments=16, min_segment_len=4, **kw)
             assert ctx.consensus(b) == exp
-            if b is full:
-                assert ctx.timings()["merge_segments"] > 3 * b.n_targets       # the cuts were really used
+            assert ctx.timings()["merge_segments"] > 3 * b.n_targets       # the cuts were really used
     # and the merged graph itself, vertex by vertex
-    batch = full
     ctx = gpu_ctx_factory(min_cov=0, min_len=0, trim=0, min_weight=0, max_segments=16, min_segment_len=4,
                           flags=capi.FLAG_STOP_AFTER_MERGE)
     ctx.consensus(batch)
@@ -1018,19 +1014,44 @@ def test_cli_polish_rounds(tmp_path):
 # ---- round 3: the parity holes round 2 exposed ------------------------------------------------
 
 @pytest.mark.parametrize("seed", [417, 463])
-def test_short_pieces_are_not_taken_on_partial_spans(seed, monkeypatch):
-    """tools/stress.py seeds 417 and 463, round 4 (26 - 30 targets of 0.7 - 9 kb at span 0.6, -t 300), the setting
-    max_segments 64 with min_segment_len 4 / 64: at the end of round 3 one run in six of exactly this ended in a GPU memory
-    fault or DAGCON_ERR_INTERNAL, the same inputs passing otherwise -- a race between the workers of such short pieces on
-    the partial-span path, there since round 2 and not understood.  Since then partial-span batches never get pieces
-    shorter than the automatic ones (dg_plan_pieces), whatever the caller asks for: the setting runs here with every buffer
-    the kernels fill poisoned, three times over (tests/test_abi.py has the plan's side of it)."""
+def test_a_cut_vertex_that_a_read_start_could_merge_with(seed, monkeypatch):
+    """tools/stress.py seeds 417 and 463, round 4 (26 - 30 targets of 0.7 - 9 kb at span 0.6, -t 300) with max_segments
+    64 and min_segment_len 4 / 64: round 2's generalized cuts took a backbone vertex v for a cut although a read started at
+    v's successor with a leading insertion of v's base -- mergeInNodes(successor) then unites v with that vertex, from the
+    worker BEHIND the cut, while the worker in front is still to run mergeInNodes(v) (k_cuts2, condition (5)).  With
+    pieces that short the two workers met: a merged graph that differed from run to run (and from the oracle's in every
+    run), bestPath stuck or out of bounds on it -- one run in six ended in a GPU fault or DAGCON_ERR_INTERNAL.  Here: the
+    merged graph of every target against the oracle's, vertex by vertex and list order included, three runs over, with
+    every buffer the kernels fill poisoned; then the consensus of the setting."""
     import os
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     import stress
     monkeypatch.setenv("DAGCON_POISON", "15")
     b, desc, min_cov, min_len, trim, kws = stress.make_round(seed, 4)
+    oracle_graphs = {}
+    for rep in range(3):
+        ctx = capi.Context(min_cov=min_cov, min_len=min_len, trim=trim, flags=capi.FLAG_STOP_AFTER_MERGE, **kws[2])
+        try:
+            ctx.consensus(b, strict=False)
+            assert ctx.timings()["merge_segments"] > 20 * b.n_targets           # the short pieces were really used
+            for t in range(b.n_targets):
+                if ctx.target_status[t] != 0:
+                    continue
+                got = ctx.debug_graph(t)
+                if t not in oracle_graphs:
+                    oracle_graphs[t] = _oracle_graph(b, t, min_len, trim, True)
+                exp, o2d = oracle_graphs[t]
+                assert len(got) == len(exp)
+                for o, (eb, ew, ec, ed, eoe, eie) in enumerate(exp):
+                    g = got[o2d[o]]
+                    assert g["deleted"] == ed, (rep, t, o2d[o])
+                    if ed:
+                        continue
+                    assert g["weight"] == ew and [(d, c) for d, c in g["out"]] == [(o2d[d], c) for d, c in eoe], (rep, t, o2d[o])
+                    assert list(g["inn"]) == [o2d[x[0]] if isinstance(x, tuple) else o2d[x] for x in eie], (rep, t, o2d[o])
+        finally:
+            ctx.close()
     exp = oracle_batch(b, min_cov, min_len, trim)
     for rep in range(3):
         ctx = capi.Context(min_cov=min_cov, min_len=min_len, trim=trim, **kws[2])
