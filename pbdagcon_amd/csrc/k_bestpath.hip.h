@@ -507,13 +507,18 @@ __global__ __launch_bounds__(64) void k_bp_sweep(DgParams p) {
 // ---- the same recurrence with a ROW of eight lanes per piece (full-span pileups, round 3) ----------------------------
 // k_bp_sweep gives a wave to a piece and scores one vertex at a time with the out-edges on its lanes: 1.5 lanes busy, 116
 // instructions issued per live vertex, and the kernel is bound by exactly that.  Here a wave sweeps eight pieces at once,
-// one per row of eight lanes (as k_merge_q does for the merge): a step scores one vertex per row -- the vertex's record and
-// final flag (the same address on the row's lanes: one request), its out-edges one per lane, their successors' scores and
-// target terms one per lane, then the first maximum in list order with a strict '>' (AlnGraphBoost.cpp:399-416) as a
-// maximum over the row and the lowest lane that holds it.  The fp32 operations per edge are dg_bp_sweep's, so are the
-// bits.  A successor that has no score yet (an edge the merge turned around: 6 % of the live vertices have one) is scored
-// first, from a small stack of the row's own in LDS; a row that runs out of stack, meets a vertex with more out-edges than
-// it has lanes, or spends its step budget marks its piece (bp_stat < 0) and k_bp_sweep does that piece over.
+// one per row of eight lanes (as k_merge_q does for the merge).  A step scores one vertex per row: five words of the vertex
+// (lens, flags, out_off, the final flag of its score, its own target term) fetched by lanes 0 .. 4 in one load and read off
+// those lanes; its out-edges one per lane; the successors' (score, target term) from a 32-entry ring of the row's finished
+// vertices in LDS (99 % of the forward edges reach at most 17 ids ahead), else from HBM; then the first maximum in list
+// order with a strict '>' (AlnGraphBoost.cpp:399-416) as the row's maximum and the lowest lane that holds it, whose value
+// is taken as it stands.  The fp32 operations per edge are dg_bp_sweep's, so are the bits.  A successor that has no score
+// yet (an edge the merge turned around: 6 % of the live vertices have one) is scored first, from a small stack of the
+// row's own in LDS; a row that runs out of stack, meets a vertex with more out-edges than it has lanes, or spends its step
+// budget marks its piece (bp_stat < 0) and k_bp_sweep does that piece over.  Finished scores are held back in LDS and
+// written eight at a time, one per lane (a step that waits for its loads would wait for the previous step's stores with
+// them: gfx950 counts both in vmcnt); the stream's next vertex has its edges on the way and the one behind it its words;
+// lanes 5 .. 7 of the fetch bring the flags of the three ids below, and the stream steps over the ones the merge deleted.
 // Scores are relative to the piece's upper cut, as there (k_bp_check verifies the exactness of that from bp_stat).
 // What steers a row lives in vector registers (see k_emit for why).
 // (A LANE per piece -- 64 pieces a wave, plain sequential code -- was built first: exact, and 8 - 14 ms instead of 4.7:
