@@ -1189,7 +1189,7 @@ __global__ __launch_bounds__(PF ? 128 : 64) __attribute__((amdgpu_waves_per_eu(8
 // entry.  Entries are taken by ticket, so a worker that waits for the earlier segments of its target
 #define DG_NOSEG_END 0xFFFFFFFFu
 #ifndef DG_ML_WAVES
-#define DG_ML_WAVES 8
+#define DG_ML_WAVES 7           // (config-5 shape, 400 targets: 5 / 6 / 7 / 8 waves per SIMD -> merge 15.5 / 14.1 / 13.7 / 14.1 ms; 74 / 74 / 109 / 180 SGPR spills)
 #endif
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DG_ML_WAVES, DG_ML_WAVES))) void k_merge_list(DgParams p) {
     if (dg_failed(p)) return;
