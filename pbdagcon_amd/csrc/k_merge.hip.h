@@ -1227,7 +1227,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DG_ML_WAVES,
 //       rewritten by two workers: such lists are shared like enter's (k_cuts2 finds them);
 //   (4) the dead ends in front of v (the insertion run a read ends with leads to exit only) are done before
 //       v: a read that ends at e < p with a trailing run of r vertices needs p - e > r + 1;
-//   (5) no read STARTS at a backbone successor of v (round 3).  Behind a full-span cut every vertex descends from v, so
+//   (5) no read STARTS behind v up to and including v's backbone successors (round 3).  Behind a full-span cut every vertex descends from v, so
 //       v has an out-edge towards every predecessor of its successors and can never be a member of a merge group
 //       there.  A read that starts at position q with a leading insertion puts a vertex c that hangs on enter in front
 //       of bb(q); if bb(q) is v's successor (q = p + 1, or further on behind deletions), every read through v goes on to
@@ -1235,8 +1235,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DG_ML_WAVES,
 //       deletes v) while the worker in front of it is still to run mergeInNodes(v): tools/stress.py seeds 417 / 463
 //       found it at the end of round 3, with pieces so short that the two workers met (a different merged graph from
 //       run to run, bestPath stuck or out of bounds on it) -- and with long pieces the worker behind always came
-//       first, which is not the reference's order either.  (v's successors only ever get fewer: merging re-points an
-//       edge to a victim at the survivor, which is a successor already);
+//       first, which is not the reference's order either.  The same with a read that starts in between, where the reads
+//       through v all delete a stretch (p, q): its vertex bb(q - 1) is a predecessor of bb(q) that does not descend from v
+//       either.  So: for every backbone successor bb(q) of v, no read has its first match in (p, q] -- then every
+//       predecessor of v's successors descends from v, v has an out-edge towards it, and v cannot be a member of a
+//       group behind the cut, the full-span argument.  (v's successors only ever get fewer: merging re-points an edge to
+//       a victim at the survivor, which is a successor already);
 // and the two vertices every segment touches, enter (out-list) and exit (in-list), follow the protocol
 // described at DgGraph::sh; exit itself is visited last of all, by k_merge_fin.  Every worker still
 // checks that it dequeues no vertex of another segment and that its FIFO is empty when it reaches its
@@ -1319,7 +1323,7 @@ __global__ __launch_bounds__(64) void k_cuts2(DgParams p) {
                             const uint32_t dd = pl_[nv.out_off + 2u * e];
                             if (dd == p.n_nodes[t] - 1u || !(nd[dd].flags & DG_NF_BACKBONE)) continue;
                             const uint32_t q = (uint32_t)nd[dd].bbpos;
-                            for (uint32_t d = 0; d < nstart && ok; d++) ok = s_start[d] != q;
+                            for (uint32_t d = 0; d < nstart && ok; d++) ok = !(s_start[d] > pos && s_start[d] <= q);
                         }
                     }
                 }
