@@ -56,7 +56,7 @@ static DgPlan dg_plan_pieces(const DgPlanIn &in) {
                                              // the balance (config-5 shape, 1,000 targets: 8 / 32 / 64 pieces 54 / 34 / 31 ms)
     else { uint32_t sm = T ? 8192u / T : 8u; pl.seg_max = sm < 8u ? 8u : sm > 256u ? 256u : sm; }
     if (in.gcuts && !in.min_segment_len) pl.seg_min = 256;
-    // k_merge_q (four segments per wave, DQ_WAVES waves per SIMD) for full-span batches big enough to fill the chip with
+    // k_merge_q (DQ_ROWS segments per wave, DQ_WAVES waves per SIMD) for full-span batches big enough to fill the chip with
     // it: as many pieces as go (<= 256 per target) with its waves filling the chip a whole number of times -- a last round
     // that is a third full costs as much as a full one (configs[1]: 36 / 49 / 56 / 64 pieces 20.6 / 17.4 / 19.2 / 18.3 ms)
     pl.use_q = 0;
@@ -109,7 +109,7 @@ struct Ctx {
     int align2 = 0;                                // (make experiments) k_align_adapt2: two pairs per wave, DAGCON_ALIGN2=1
     int fold = 1;                                  // duplicate insertion chains folded by k_emit (DAGCON_FOLD=0: never)
     int list_q = 0;                                // (make experiments) partial-span worklist by rows, k_merge_list_q: DAGCON_MERGE_LIST_Q=1
-    int merge_q = 1, use_q = 0;                    // k_merge_q: four segments per wave (DAGCON_MERGE_Q=0: never); this batch
+    int merge_q = 1, use_q = 0;                    // k_merge_q: eight segments per wave (DAGCON_MERGE_Q=0: never); this batch
     uint32_t max_k = 0, max_tlen = 0;
     uint64_t sum_len = 0, sum_bb = 0, mat_cells = 0, blob_bytes = 0;
     bool have_bb = false;
@@ -527,7 +527,7 @@ int dagcon_create(const dagcon_opts *opts, dagcon_ctx **out) {
     if (const char *e = getenv("DAGCON_EMIT2")) c->emit2 = atoi(e) != 0;
 #endif
     if (const char *e = getenv("DAGCON_MERGE_LIST_Q")) c->list_q = atoi(e) != 0;
-    if (const char *e = getenv("DAGCON_MERGE_Q")) c->merge_q = atoi(e) != 0;     // four segments per wave (k_merge_q.hip.h)
+    if (const char *e = getenv("DAGCON_MERGE_Q")) c->merge_q = atoi(e) != 0;     // eight segments per wave (k_merge_q.hip.h)
     memset(&c->tm, 0, sizeof c->tm);
     memset(&c->h_st, 0, sizeof c->h_st);
     if (hipSetDevice(c->device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {

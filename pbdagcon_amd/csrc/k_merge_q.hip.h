@@ -1,9 +1,9 @@
-// k_merge_q.hip.h -- mergeNodes (AlnGraphBoost.cpp:129-273) with FOUR segments per wave.
+// k_merge_q.hip.h -- mergeNodes (AlnGraphBoost.cpp:129-273) with EIGHT segments per wave (round 2: four).
 //
 // k_merge (k_merge.hip.h) gives a wave to one segment between two cut vertices and uses, on a typical visit, 2 - 4 of
 // its 64 lanes: the kernel is bound by instruction issue, and almost all of the instructions are bookkeeping that
-// does not care how many lanes take part.  Here a wave sweeps four segments at once, one per 16-lane row: the code
-// is the same sweep, written for a row -- a list entry per lane of the row, ballots cut down to the row's 16 bits,
+// does not care how many lanes take part.  Here a wave sweeps DQ_ROWS segments at once, one per row of DQ_W lanes (8 x 8 since round 3; 4 x 16 in round 2): the code
+// is the same sweep, written for a row -- a list entry per lane of the row, ballots cut down to the row's bits,
 // cross-lane reads through the row (ds_bpermute), per-row state in vector registers -- so one instruction serves
 // four visits as long as the rows do the same thing.  When one row merges and the others do not, the others wait
 // (the wave executes the union of its rows' paths); lists longer than a row take the reference-literal
