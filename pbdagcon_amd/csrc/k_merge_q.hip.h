@@ -5,7 +5,7 @@
 // does not care how many lanes take part.  Here a wave sweeps DQ_ROWS segments at once, one per row of DQ_W lanes (8 x 8 since round 3; 4 x 16 in round 2): the code
 // is the same sweep, written for a row -- a list entry per lane of the row, ballots cut down to the row's bits,
 // cross-lane reads through the row (ds_bpermute), per-row state in vector registers -- so one instruction serves
-// four visits as long as the rows do the same thing.  When one row merges and the others do not, the others wait
+// DQ_ROWS visits as long as the rows do the same thing.  When one row merges and the others do not, the others wait
 // (the wave executes the union of its rows' paths); lists longer than a row take the reference-literal
 // single-lane path (dgg_*), as lists longer than a wave do in k_merge.
 //
